@@ -1,0 +1,167 @@
+/*
+ * hoqp.h -- C ABI of the MI355X-native batched hierarchical-QP (HO-QP) solver.
+ *
+ * Drop-in boundary for the solve step of control::HoQpProblem / control::HoQpController
+ * of bernhardpg/quadruped_locomotion.  The reference has no FFI layer for this path: the
+ * boundary it exposes is the C++ class API (include/control/ho_qp/ho_qp_problem.hpp:23-43,
+ * include/control/ho_qp/ho_qp_controller.hpp:27-44).  Each entry point below cites the
+ * reference interface it replaces (paths relative to the reference root).  The C++ shim
+ * include/hoqp.hpp re-creates TaskDefinition / HoQpProblem / HoQpController on top of it.
+ *
+ * All pointers inside *_batch / *_inputs / *_outputs structs are DEVICE pointers
+ * (hipMalloc memory) unless stated otherwise.  Matrices are dense, row-major, fp64.
+ * Batched arrays are instance-major: the block of one instance is contiguous, so the
+ * one-workgroup-per-instance kernels read them with fully coalesced loads.
+ *
+ * Every function returns 0 on success, <0 on an argument / dimension / HIP error
+ * (hoqp_last_error_string gives the text); per-instance solver outcomes go to the
+ * `status` output array, never to abort()/assert (the reference only asserts,
+ * src/control/ho_qp/ho_qp_problem.cpp:348).
+ */
+#ifndef HOQP_H
+#define HOQP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HOQP_MAX_LEVELS 8   /* priority levels per hierarchy */
+#define HOQP_MAX_VARS 32    /* decision variables n (ANYmal: 18 + 3 n_c <= 30) */
+#define HOQP_MAX_EQ_ROWS 32 /* equality rows of one level */
+#define HOQP_MAX_INEQ_ROWS 64 /* inequality rows summed over all levels */
+
+/* Semantics switches: the reference's behavioural quirks. */
+#define HOQP_Q1_FRICTION_COLS 0x01 /* friction pyramid on columns 6+3*leg, ho_qp_controller.cpp:321-324 */
+#define HOQP_Q2_GATE_PRIOR_INEQ 0x02 /* prior inequality rows only if the level has its own, ho_qp_problem.cpp:297-298 */
+#define HOQP_Q3_SLACK_ORDER 0x04 /* rows newest-first vs slacks oldest-first, ho_qp_problem.cpp:83-101 */
+#define HOQP_Q5_DROP_BASE_POS_GAIN 0x10 /* stray ';' at ho_qp_controller.cpp:236 */
+#define HOQP_Q6_ZERO_KERNEL_COL 0x20 /* Eigen kernel() of a full-column-rank matrix (shim level only) */
+#define HOQP_SEMANTICS_REFERENCE 0x37
+#define HOQP_SEMANTICS_PAPER 0x00
+
+/* per-instance status bits */
+#define HOQP_STATUS_OK 0
+#define HOQP_STATUS_MAX_ITER 0x01	 /* active-set iteration cap hit at some level (iterate is feasible) */
+#define HOQP_STATUS_INFEASIBLE_START 0x02 /* a prior (hard) row was violated when a level started */
+#define HOQP_STATUS_WORKSPACE 0x04	 /* working set outgrew the LDS workspace */
+#define HOQP_STATUS_NONFINITE 0x08	 /* NaN/Inf in the inputs or the solution */
+#define HOQP_STATUS_UNSUPPORTED 0x10	 /* Q3 pairing with >= 3 inequality levels */
+
+typedef struct hoqp_handle hoqp_handle;
+
+typedef struct {
+	int device;	/* HIP device ordinal the handle is bound to */
+	int semantics;	/* HOQP_Q* bitmask */
+	double eps;	/* eps_ of ho_qp_problem.hpp:56 (1e-12) */
+	int max_iter;	/* active-set iterations per level */
+	/* HoQpController constants, ho_qp_controller.hpp:54-56 and the gains of
+	 * ho_qp_controller.cpp:191-192, 224-225, 259-260 */
+	double mu, tau_max, tau_min;
+	double kp_swing, kv_swing, kp_base, kv_base, kv_rot;
+} hoqp_config;
+
+/* Replaces: the compile-time constants of HoQpController / HoQpProblem. */
+void hoqp_default_config(hoqp_config *cfg);
+
+/* Replaces: HoQpController::HoQpController (ho_qp_controller.cpp:5).  One handle per host
+ * thread and GPU; handles share no mutable state. */
+int hoqp_create(const hoqp_config *cfg, hoqp_handle **out);
+int hoqp_destroy(hoqp_handle *h);
+const char *hoqp_last_error_string(const hoqp_handle *h);
+
+/*
+ * A batch of task hierarchies: level k of instance i is TaskDefinition{A,b,D,f}
+ * (include/control/ho_qp/task_definition.hpp:5-11).  Storage of level k:
+ *   A[k]: [batch][m[k]][n]   b[k]: [batch][m[k]]   D[k]: [batch][p[k]][n]   f[k]: [batch][p[k]]
+ * m[k] / p[k] / n are the STORAGE extents (0 = level has no such block).  If n_inst /
+ * m_inst / p_inst are non-NULL, instance i uses only the leading n_inst[i] columns and
+ * m_inst[i*num_levels+k] / p_inst[...] rows (variable constraint counts per instance).
+ */
+typedef struct {
+	int batch, n, num_levels;
+	int m[HOQP_MAX_LEVELS], p[HOQP_MAX_LEVELS];
+	const double *A[HOQP_MAX_LEVELS], *b[HOQP_MAX_LEVELS];
+	const double *D[HOQP_MAX_LEVELS], *f[HOQP_MAX_LEVELS];
+	const int *n_inst, *m_inst, *p_inst;
+} hoqp_task_batch;
+
+/* Any pointer may be NULL (that output is skipped).  P = sum_k p[k]. */
+typedef struct {
+	double *x;	   /* [batch][n]   HoQpProblem::GetSolution of the last level (ho_qp_problem.cpp:46-51) */
+	double *x_levels;  /* [batch][L][n] GetSolution of every level */
+	double *v;	   /* [batch][P]   GetStackedSlackSolutions, oldest level first (:58-61, 88-101) */
+	double *level_res; /* [batch][L]   |A_k x_k - b_k|_2 at the level's own optimum */
+	double *Z_levels;  /* [batch][L][n][n] GetStackedNullspaceMatrix (leading nz columns, orthonormal basis) */
+	int *nz_levels;	   /* [batch][L]   columns of Z_k */
+	int *iters;	   /* [batch][L]   active-set iterations */
+	int *status;	   /* [batch]      HOQP_STATUS_* */
+	/* CheckSolutionValid at the FINAL x (include/helper_functions.hpp:63-91): */
+	int *flags;	   /* [batch][L] 1 = "Solution valid" (|Ax-b| <= 1e-7 and Dx-f <= 0) */
+	double *eq_res_max;    /* [batch][L] max |A_k x - b_k| */
+	double *ineq_viol_max; /* [batch][L] max (D_k x - f_k) */
+	unsigned long long *active_mask; /* [batch] bit r: stacked inequality row r has D x - f >= -1e-7 */
+} hoqp_result_batch;
+
+/*
+ * Replaces: the chain of HoQpProblem constructors built by
+ * HoQpController::ConstructOptProblems (ho_qp_controller.cpp:120-141), i.e. for every
+ * level the pipeline of HoQpProblem::HoQpProblem (ho_qp_problem.cpp:11-25), including
+ * drake::solvers::Solve (:339) and CalcNullSpaceProjMatrix (math.hpp:99-104).
+ * Asynchronous on `stream` (a hipStream_t, may be NULL).
+ */
+int hoqp_solve_tasks_batched(hoqp_handle *h, const hoqp_task_batch *tasks, const hoqp_result_batch *out,
+			     void *stream);
+
+/*
+ * What HoQpController::UpdateModelDynamics (ho_qp_controller.cpp:89-114), SetBaseCmd
+ * (:27-36) and SetLegCmd (:38-65) hand to the solve, per instance:
+ *   M [18][18], h [18], Jfoot [4][3][18] (translational foot Jacobians, legs LF,RF,LH,RH),
+ *   Jdotu [4][3], footpos [4][3], Jb [6][18] (rows 0-2 rot, 3-5 pos; NULL = [I6 0]),
+ *   q [19], u [18], base_cmd [9] (pos,vel,acc), leg_cmd [36] (pos,vel,acc x 12),
+ *   contact [4] ints (1 = contact, 0 = swing).
+ */
+typedef struct {
+	int batch;
+	const double *M, *h, *Jfoot, *Jdotu, *footpos, *Jb, *q, *u, *base_cmd, *leg_cmd;
+	const int *contact;
+} hoqp_wbc_inputs;
+
+typedef struct {
+	double *x;	/* [batch][30] solution_, zero padded beyond n = 18 + 3 n_c */
+	double *qdd;	/* [batch][12] GetJointAccelerationCmd (ho_qp_controller.cpp:23, 80-83) */
+	double *tau;	/* [batch][12] GetJointTorqueCmd (:67-78) */
+	double *v;	/* [batch][40] slack of the torque/friction level */
+	int *flags;	/* [batch][5]  the five CheckSolutionValid results of CalcJointCmd (:18-22) */
+	double *eq_res_max, *ineq_viol_max, *level_res; /* [batch][5] */
+	unsigned long long *active_mask;		/* [batch] */
+	int *status, *iters, *nz_levels;		/* [batch], [batch][5], [batch][5] */
+	double *x_levels;				/* [batch][5][30] */
+} hoqp_wbc_outputs;
+
+/*
+ * Replaces: HoQpController::CalcJointCmd after UpdateModelDynamics
+ * (ho_qp_controller.cpp:7-25): ConstructTasks (:147-184) with its nine builders
+ * (:186-400), ConstructOptProblems (:120-141), the five CheckSolutionValid calls and
+ * CalcJointTorquesCmd (:67-73).  Mixed contact patterns are handled per instance.
+ */
+int hoqp_solve_wbc_batched(hoqp_handle *h, const hoqp_wbc_inputs *in, const hoqp_wbc_outputs *out, void *stream);
+
+/* Blocks until `stream` has drained; returns <0 if a kernel faulted. */
+int hoqp_synchronize(hoqp_handle *h, void *stream);
+
+/* Average device time (ms) of the solve kernel over the launches recorded since the last
+ * call with reset != 0; measured with HIP events on the launch stream.  Used by bench.py. */
+int hoqp_kernel_time_ms(hoqp_handle *h, int reset, double *avg_ms, int *launches);
+
+/* Device self-test of the wavefront primitives (reductions, broadcasts).  0 = pass. */
+int hoqp_selftest(hoqp_handle *h);
+
+/* LDS bytes per workgroup the solve kernel needs for these extents (0 on error). */
+size_t hoqp_lds_bytes(int n, int num_levels, const int *m, const int *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HOQP_H */

@@ -82,6 +82,9 @@ def default_cfg(mode: str = "reference", nullspace: str | None = None) -> Cfg:
         cfg.slack_order_quirk = 0
         cfg.zero_kernel_col = 0
         cfg.nullspace_basis = 1
+        # "paper" = the algorithm without the reference's eps_*I regulariser; the oracle needs a
+        # tiny positive value for its pivot floor (100*eps), 1e-15 is below fp64 resolution here.
+        cfg.eps = 1e-15
     elif mode != "reference":
         raise ValueError(mode)
     if nullspace == "householder":

@@ -1,0 +1,291 @@
+"""ctypes binding of the C ABI in include/hoqp.h (libhoqp_hip.so, gfx950 HIP kernels).
+
+PyTorch is used only as the owner of device memory and streams; every solve goes
+through the C ABI with raw device pointers.  There is no CPU fallback: if the HIP
+library is missing or no GPU is present, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhoqp_hip.so")
+
+MAX_LEVELS = 8
+MAX_VARS = 32
+MAX_EQ_ROWS = 32
+MAX_INEQ_ROWS = 64
+
+Q1_FRICTION_COLS = 0x01
+Q2_GATE_PRIOR_INEQ = 0x02
+Q3_SLACK_ORDER = 0x04
+Q5_DROP_BASE_POS_GAIN = 0x10
+Q6_ZERO_KERNEL_COL = 0x20
+SEMANTICS_REFERENCE = 0x37
+SEMANTICS_PAPER = 0x00
+
+STATUS_MAX_ITER = 0x01
+STATUS_INFEASIBLE_START = 0x02
+STATUS_WORKSPACE = 0x04
+STATUS_NONFINITE = 0x08
+
+EXPORTS = (
+    "hoqp_default_config", "hoqp_create", "hoqp_destroy", "hoqp_last_error_string",
+    "hoqp_solve_tasks_batched", "hoqp_solve_wbc_batched", "hoqp_synchronize",
+    "hoqp_kernel_time_ms", "hoqp_selftest", "hoqp_lds_bytes",
+)
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_up = C.POINTER(C.c_ulonglong)
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int), ("semantics", C.c_int), ("eps", C.c_double), ("max_iter", C.c_int),
+                ("mu", C.c_double), ("tau_max", C.c_double), ("tau_min", C.c_double),
+                ("kp_swing", C.c_double), ("kv_swing", C.c_double), ("kp_base", C.c_double),
+                ("kv_base", C.c_double), ("kv_rot", C.c_double)]
+
+
+class TaskBatch(C.Structure):
+    _fields_ = [("batch", C.c_int), ("n", C.c_int), ("num_levels", C.c_int),
+                ("m", C.c_int * MAX_LEVELS), ("p", C.c_int * MAX_LEVELS),
+                ("A", C.c_void_p * MAX_LEVELS), ("b", C.c_void_p * MAX_LEVELS),
+                ("D", C.c_void_p * MAX_LEVELS), ("f", C.c_void_p * MAX_LEVELS),
+                ("n_inst", C.c_void_p), ("m_inst", C.c_void_p), ("p_inst", C.c_void_p)]
+
+
+class ResultBatch(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("x_levels", C.c_void_p), ("v", C.c_void_p), ("level_res", C.c_void_p),
+                ("Z_levels", C.c_void_p), ("nz_levels", C.c_void_p), ("iters", C.c_void_p),
+                ("status", C.c_void_p), ("flags", C.c_void_p), ("eq_res_max", C.c_void_p),
+                ("ineq_viol_max", C.c_void_p), ("active_mask", C.c_void_p)]
+
+
+class WbcInputs(C.Structure):
+    _fields_ = [("batch", C.c_int), ("M", C.c_void_p), ("h", C.c_void_p), ("Jfoot", C.c_void_p),
+                ("Jdotu", C.c_void_p), ("footpos", C.c_void_p), ("Jb", C.c_void_p), ("q", C.c_void_p),
+                ("u", C.c_void_p), ("base_cmd", C.c_void_p), ("leg_cmd", C.c_void_p), ("contact", C.c_void_p)]
+
+
+class WbcOutputs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("qdd", C.c_void_p), ("tau", C.c_void_p), ("v", C.c_void_p),
+                ("flags", C.c_void_p), ("eq_res_max", C.c_void_p), ("ineq_viol_max", C.c_void_p),
+                ("level_res", C.c_void_p), ("active_mask", C.c_void_p), ("status", C.c_void_p),
+                ("iters", C.c_void_p), ("nz_levels", C.c_void_p), ("x_levels", C.c_void_p)]
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libhoqp_hip.so and declare prototypes.  Raises if it was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} not found: build it with __graft_entry__.build() "
+                               "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        # torch bundles its own libamdhip64.so.7; it must be in the process first so that this
+        # library binds to the SAME HIP runtime (two runtimes in one process do not share devices,
+        # streams or allocations).
+        import torch  # noqa: F401
+
+        lib = C.CDLL(LIB_PATH)
+        lib.hoqp_default_config.argtypes = [C.POINTER(Config)]
+        lib.hoqp_default_config.restype = None
+        lib.hoqp_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
+        lib.hoqp_destroy.argtypes = [C.c_void_p]
+        lib.hoqp_last_error_string.argtypes = [C.c_void_p]
+        lib.hoqp_last_error_string.restype = C.c_char_p
+        lib.hoqp_solve_tasks_batched.argtypes = [C.c_void_p, C.POINTER(TaskBatch), C.POINTER(ResultBatch), C.c_void_p]
+        lib.hoqp_solve_wbc_batched.argtypes = [C.c_void_p, C.POINTER(WbcInputs), C.POINTER(WbcOutputs), C.c_void_p]
+        lib.hoqp_synchronize.argtypes = [C.c_void_p, C.c_void_p]
+        lib.hoqp_kernel_time_ms.argtypes = [C.c_void_p, C.c_int, _dp, _ip]
+        lib.hoqp_selftest.argtypes = [C.c_void_p]
+        lib.hoqp_lds_bytes.argtypes = [C.c_int, C.c_int, _ip, _ip]
+        lib.hoqp_lds_bytes.restype = C.c_size_t
+        _lib = lib
+    return _lib
+
+
+def default_config(mode: str = "reference", device: int = 0, **kw) -> Config:
+    cfg = Config()
+    load_library().hoqp_default_config(C.byref(cfg))
+    cfg.device = device
+    if mode == "paper":
+        cfg.semantics = SEMANTICS_PAPER
+        cfg.eps = 0.0
+    elif mode != "reference":
+        raise ValueError(mode)
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def lds_bytes(n, m, p):
+    L = len(m)
+    return load_library().hoqp_lds_bytes(n, L, (C.c_int * L)(*m), (C.c_int * L)(*p))
+
+
+WBC_M = (6, 0, 12, 18, 12)
+WBC_P = (0, 40, 0, 0, 0)
+
+
+class HoQpSolver:
+    """One handle == one GPU == one host thread (include/hoqp.h)."""
+
+    def __init__(self, cfg: Config | None = None):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("HoQpSolver needs a HIP device (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback")
+        self.lib = load_library()
+        self.cfg = cfg or default_config()
+        self.torch = torch
+        self.device = torch.device("cuda", self.cfg.device)
+        h = C.c_void_p()
+        rc = self.lib.hoqp_create(C.byref(self.cfg), C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"hoqp_create failed: {rc}")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.hoqp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self.lib.hoqp_last_error_string(self.h)
+            raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def selftest(self):
+        self._check(self.lib.hoqp_selftest(self.h), "hoqp_selftest")
+
+    def synchronize(self):
+        self._check(self.lib.hoqp_synchronize(self.h, self._stream()), "hoqp_synchronize")
+
+    def timing(self, enable: bool):
+        self._check(self.lib.hoqp_kernel_time_ms(self.h, 1 if enable else 2, None, None), "hoqp_kernel_time_ms")
+
+    def kernel_time_ms(self):
+        avg = C.c_double(0)
+        cnt = C.c_int(0)
+        self._check(self.lib.hoqp_kernel_time_ms(self.h, 0, C.byref(avg), C.byref(cnt)), "hoqp_kernel_time_ms")
+        return avg.value, cnt.value
+
+    # -- generic hierarchy -------------------------------------------------
+    def alloc_task_outputs(self, batch, n, m, p, debug=False):
+        t, dev = self.torch, self.device
+        L, P = len(m), max(1, int(sum(p)))
+        o = dict(x=t.zeros(batch, n, dtype=t.float64, device=dev),
+                 x_levels=t.zeros(batch, L, n, dtype=t.float64, device=dev),
+                 v=t.zeros(batch, P, dtype=t.float64, device=dev),
+                 level_res=t.zeros(batch, L, dtype=t.float64, device=dev),
+                 nz_levels=t.zeros(batch, L, dtype=t.int32, device=dev),
+                 iters=t.zeros(batch, L, dtype=t.int32, device=dev),
+                 status=t.zeros(batch, dtype=t.int32, device=dev),
+                 flags=t.zeros(batch, L, dtype=t.int32, device=dev),
+                 eq_res_max=t.zeros(batch, L, dtype=t.float64, device=dev),
+                 ineq_viol_max=t.zeros(batch, L, dtype=t.float64, device=dev),
+                 active_mask=t.zeros(batch, dtype=t.int64, device=dev))
+        if debug:
+            o["Z_levels"] = t.zeros(batch, L, n, n, dtype=t.float64, device=dev)
+        return o
+
+    def solve_tasks(self, tasks, n, out=None, n_inst=None, m_inst=None, p_inst=None, debug=False):
+        """tasks: list (priority order) of dicts with optional device tensors
+        A [B,m,n], b [B,m], D [B,p,n], f [B,p] (float64, contiguous)."""
+        t = self.torch
+        L = len(tasks)
+        tb = TaskBatch()
+        B = None
+        ms, ps = [], []
+        keep = []
+        for k, task in enumerate(tasks):
+            A, b, D, f = (task.get(key) for key in ("A", "b", "D", "f"))
+            mk = 0 if A is None else A.shape[1]
+            pk = 0 if D is None else D.shape[1]
+            for arr in (A, b, D, f):
+                if arr is not None:
+                    assert arr.dtype == t.float64 and arr.is_contiguous() and arr.is_cuda
+                    B = arr.shape[0] if B is None else B
+                    assert arr.shape[0] == B
+                    keep.append(arr)
+            tb.m[k], tb.p[k] = mk, pk
+            tb.A[k] = A.data_ptr() if mk else None
+            tb.b[k] = b.data_ptr() if mk else None
+            tb.D[k] = D.data_ptr() if pk else None
+            tb.f[k] = f.data_ptr() if pk else None
+            ms.append(mk)
+            ps.append(pk)
+        tb.batch, tb.n, tb.num_levels = B or 0, n, L
+        for name, arr in (("n_inst", n_inst), ("m_inst", m_inst), ("p_inst", p_inst)):
+            if arr is not None:
+                assert arr.dtype == t.int32 and arr.is_contiguous() and arr.is_cuda
+                setattr(tb, name, arr.data_ptr())
+        if out is None:
+            out = self.alloc_task_outputs(B or 0, n, ms, ps, debug)
+        rb = ResultBatch()
+        for name, _ in ResultBatch._fields_:
+            if name in out and out[name] is not None:
+                setattr(rb, name, out[name].data_ptr())
+        self._check(self.lib.hoqp_solve_tasks_batched(self.h, C.byref(tb), C.byref(rb), self._stream()),
+                    "hoqp_solve_tasks_batched")
+        return out
+
+    # -- whole-body controller ---------------------------------------------
+    def alloc_wbc_outputs(self, batch):
+        t, dev = self.torch, self.device
+        return dict(x=t.zeros(batch, 30, dtype=t.float64, device=dev),
+                    qdd=t.zeros(batch, 12, dtype=t.float64, device=dev),
+                    tau=t.zeros(batch, 12, dtype=t.float64, device=dev),
+                    v=t.zeros(batch, 40, dtype=t.float64, device=dev),
+                    flags=t.zeros(batch, 5, dtype=t.int32, device=dev),
+                    eq_res_max=t.zeros(batch, 5, dtype=t.float64, device=dev),
+                    ineq_viol_max=t.zeros(batch, 5, dtype=t.float64, device=dev),
+                    level_res=t.zeros(batch, 5, dtype=t.float64, device=dev),
+                    active_mask=t.zeros(batch, dtype=t.int64, device=dev),
+                    status=t.zeros(batch, dtype=t.int32, device=dev),
+                    iters=t.zeros(batch, 5, dtype=t.int32, device=dev),
+                    nz_levels=t.zeros(batch, 5, dtype=t.int32, device=dev),
+                    x_levels=t.zeros(batch, 5, 30, dtype=t.float64, device=dev))
+
+    def to_device(self, inp):
+        """dict of numpy arrays (anymal_model.make_wbc_inputs) -> dict of device tensors."""
+        t = self.torch
+        return {k: t.as_tensor(v).contiguous().to(self.device) for k, v in inp.items()}
+
+    def solve_wbc(self, dinp, out=None):
+        t = self.torch
+        B = dinp["M"].shape[0]
+        wi = WbcInputs()
+        wi.batch = B
+        for name in ("M", "h", "Jfoot", "Jdotu", "footpos", "Jb", "q", "u", "base_cmd", "leg_cmd"):
+            arr = dinp.get(name)
+            if arr is not None:
+                assert arr.dtype == t.float64 and arr.is_contiguous() and arr.is_cuda, name
+                setattr(wi, name, arr.data_ptr())
+        c = dinp["contact"]
+        assert c.dtype == t.int32 and c.is_contiguous() and c.is_cuda
+        wi.contact = c.data_ptr()
+        if out is None:
+            out = self.alloc_wbc_outputs(B)
+        wo = WbcOutputs()
+        for name, _ in WbcOutputs._fields_:
+            if out.get(name) is not None:
+                setattr(wo, name, out[name].data_ptr())
+        self._check(self.lib.hoqp_solve_wbc_batched(self.h, C.byref(wi), C.byref(wo), self._stream()),
+                    "hoqp_solve_wbc_batched")
+        return out
