@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- fp64 HO-QP solves/s on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path (hoqp_solve_wbc_batched: task construction +
+5-level HO-QP chain + torque map + validity flags) over one batch of synthetic
+ANYmal-C-like states that is already resident in HBM.  N = 1 workload: BASELINE.json
+configs[1] (4096 randomised 4-contact stance states, reference semantics).  N > 1: the
+batch dimension is sharded, one process per GPU, the same 4096 states per rank (weak
+scaling); the only collective is the RCCL gather of per-instance solutions and the
+all-reduce of residual statistics to rank 0 (the path's one exchange step).
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_VEC_PEAK_TF = 78.6    # public spec figure, vector FP64
+# algorithmic bytes per solve of the dominant kernel (hoqp_solve_kernel reads the generic
+# task blocks): SURVEY.md section 8(d), generic task entry, n_c = 4: 8*76*31 in + 664 out
+ALG_BYTES_PER_SOLVE = 8 * 76 * 31 + 664
+# algorithmic flops per solve, reference mode, zero active-set iterations
+ALG_FLOPS_PER_SOLVE = 210_984
+
+
+def cpu_baseline(inp, mode, sample, threads):
+    """The oracle ("port") timed on the host cores over a bounded sample."""
+    from oracle import oracle as orc
+
+    orc.build()
+    sub = {k: v[:sample] for k, v in inp.items()}
+    cfg, prm = orc.default_cfg(mode), orc.default_wbc_params(mode)
+    orc.wbc_solve_batch({k: v[:8] for k, v in sub.items()}, cfg, prm, threads=threads)  # warm
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        orc.wbc_solve_batch(sub, cfg, prm, threads=threads)
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt > 10.0 or reps >= 50:
+            break
+    return dict(value=sample * reps / dt, unit="solves/s", cores=threads, kind="port",
+                sample=f"{reps} passes over the first {sample} states of the same batch, "
+                       f"oracle/hoqp_oracle.c (-O3, OpenMP {threads} threads); Drake/Eigen reference unbuildable")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=4096, help="states per GPU per step")
+    ap.add_argument("--mode", default="reference", choices=["reference", "paper"])
+    ap.add_argument("--contact", default="stance", choices=["stance", "trot", "three"])
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=512)
+    ap.add_argument("--no-gather", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from quadruped_locomotion_amd import anymal_model as am
+    from quadruped_locomotion_amd import hoqp
+
+    torch.cuda.set_device(local_rank)
+    solver = hoqp.HoQpSolver(hoqp.default_config(args.mode, device=local_rank))
+    inp = am.make_wbc_inputs(am.sample_states(args.batch, args.seed + rank, args.contact))
+    dinp = solver.to_device(inp)
+    out = solver.alloc_wbc_outputs(args.batch)
+    from quadruped_locomotion_amd import parallel
+
+    def step():
+        solver.solve_wbc(dinp, out)
+        if world > 1 and not args.no_gather:
+            # the path's one exchange step: per-instance solutions to rank 0 (RCCL gather),
+            # residual statistics all-reduced
+            parallel.gather_solutions(dict(x=out["x"], tau=out["tau"]), args.batch * world, dst=0)
+            mx, sm = parallel.local_stats(out)
+            parallel.reduce_stats(mx, sm)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    solver.timing(True)
+    lat = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    kern_ms, kern_n = solver.kernel_time_ms()
+    solver.timing(False)
+
+    # p50/p99 batch latency (submit -> results visible), measured outside the timed region
+    for _ in range(min(args.steps, 300)):
+        torch.cuda.synchronize()
+        a = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        lat.append((time.perf_counter() - a) * 1e3)
+    lat = np.array(lat)
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=solver.device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    status = out["status"].cpu().numpy()
+    iters = out["iters"].cpu().numpy()
+    if rank == 0:
+        total = args.batch * world * args.steps
+        value = total / elapsed
+        kern_s = kern_ms * 1e-3
+        achieved_gbs = ALG_BYTES_PER_SOLVE * args.batch / kern_s / 1e9 if kern_s > 0 else 0.0
+        res = {
+            "metric": "fp64 HO-QP solves/sec (ANYmal-C, 4 contacts)",
+            "value": value,
+            "unit": "solves/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic (own ANYmal-C-like model, seed %d)" % args.seed,
+            "config": {"workload": f"configs[1]: {args.batch} randomised {args.contact} states per GPU, "
+                                   f"5-level WBC hierarchy, {args.mode} semantics",
+                       "batch_per_gpu": args.batch, "semantics": args.mode, "contact": args.contact,
+                       "entry": "hoqp_solve_wbc_batched", "gather": bool(world > 1 and not args.no_gather)},
+            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "hoqp_solve_kernel", "kernel_ms": kern_ms, "launches_timed": kern_n,
+                         "alg_bytes_per_solve": ALG_BYTES_PER_SOLVE,
+                         "fp64_vector": {"achieved_tflops": ALG_FLOPS_PER_SOLVE * args.batch / kern_s / 1e12
+                                         if kern_s > 0 else 0.0, "peak_tflops": FP64_VEC_PEAK_TF,
+                                         "alg_flops_per_solve": ALG_FLOPS_PER_SOLVE},
+                         "note": "latency/LDS-bound small factorizations; both classical fractions are < 1 %"},
+            "latency_ms": {"p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99)),
+                           "max": float(lat.max()), "batches": int(lat.size)},
+            "solver": {"status_nonzero": int((status != 0).sum()), "iters_level1_mean": float(iters[:, 1].mean()),
+                       "iters_max": int(iters.max())},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            threads = min(16, os.cpu_count() or 1)
+            res["cpu_baseline"] = cpu_baseline(inp, args.mode, min(args.cpu_sample, args.batch), threads)
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -148,6 +148,16 @@ typedef struct {
  */
 int hoqp_solve_wbc_batched(hoqp_handle *h, const hoqp_wbc_inputs *in, const hoqp_wbc_outputs *out, void *stream);
 
+/*
+ * Host-buffer variants: every pointer in the structs is a HOST pointer; the library stages
+ * through device memory, runs the same kernels and blocks until the results are back.
+ * This is the form a drop-in for the single-instance reference API needs: HoQpProblem /
+ * HoQpController hand over host Eigen matrices (ho_qp_problem.hpp:23-27,
+ * ho_qp_controller.hpp:27-41).  PCIe-inclusive; not the benchmarked path.
+ */
+int hoqp_solve_tasks_host(hoqp_handle *h, const hoqp_task_batch *tasks, const hoqp_result_batch *out);
+int hoqp_solve_wbc_host(hoqp_handle *h, const hoqp_wbc_inputs *in, const hoqp_wbc_outputs *out);
+
 /* Blocks until `stream` has drained; returns <0 if a kernel faulted. */
 int hoqp_synchronize(hoqp_handle *h, void *stream);
 

@@ -1284,6 +1284,174 @@ extern "C" int hoqp_solve_wbc_batched(hoqp_handle *h, const hoqp_wbc_inputs *in,
 	return 0;
 }
 
+// ---------------------------------------------------------------------------
+// host-buffer convenience entry points (single-instance drop-in use: the reference calls
+// CalcJointCmd once per 2.5 ms cycle with host Eigen data, whole_body_controller.cpp:97-107)
+// ---------------------------------------------------------------------------
+namespace {
+struct DevBuf {
+	std::vector<void *> ptrs;
+	~DevBuf()
+	{
+		for (void *p : ptrs)
+			(void)hipFree(p);
+	}
+	template <typename T>
+	hipError_t up(const T *host, size_t count, const T **dev)
+	{
+		*dev = nullptr;
+		if (!host || count == 0)
+			return hipSuccess;
+		void *d = nullptr;
+		hipError_t e = hipMalloc(&d, sizeof(T) * count);
+		if (e != hipSuccess)
+			return e;
+		ptrs.push_back(d);
+		*dev = (const T *)d;
+		return hipMemcpy(d, host, sizeof(T) * count, hipMemcpyHostToDevice);
+	}
+	template <typename T>
+	hipError_t out(T *host, size_t count, T **dev)
+	{
+		*dev = nullptr;
+		if (!host || count == 0)
+			return hipSuccess;
+		void *d = nullptr;
+		hipError_t e = hipMalloc(&d, sizeof(T) * count);
+		if (e != hipSuccess)
+			return e;
+		ptrs.push_back(d);
+		*dev = (T *)d;
+		return hipMemset(d, 0, sizeof(T) * count);
+	}
+};
+template <typename T>
+hipError_t down(T *host, const T *dev, size_t count)
+{
+	if (!host || !dev || count == 0)
+		return hipSuccess;
+	return hipMemcpy(host, dev, sizeof(T) * count, hipMemcpyDeviceToHost);
+}
+}  // namespace
+
+extern "C" int hoqp_solve_tasks_host(hoqp_handle *h, const hoqp_task_batch *t, const hoqp_result_batch *o)
+{
+	if (!h)
+		return -1;
+	if (!t || !o)
+		return fail(h, -1, "null argument");
+	if (t->batch < 0 || t->n < 1 || t->n > HOQP_MAX_VARS || t->num_levels < 1 || t->num_levels > HOQP_MAX_LEVELS)
+		return fail(h, -1, "bad extents");
+	HIP_OK(h, hipSetDevice(h->cfg.device));
+	DevBuf buf;
+	hoqp_task_batch dt = *t;
+	const size_t B = t->batch, n = t->n, L = t->num_levels;
+	size_t P = 0;
+	for (size_t k = 0; k < L; ++k) {
+		if (t->m[k] < 0 || t->p[k] < 0)
+			return fail(h, -1, "negative row count");
+		HIP_OK(h, buf.up(t->A[k], B * t->m[k] * n, &dt.A[k]));
+		HIP_OK(h, buf.up(t->b[k], B * t->m[k], &dt.b[k]));
+		HIP_OK(h, buf.up(t->D[k], B * t->p[k] * n, &dt.D[k]));
+		HIP_OK(h, buf.up(t->f[k], B * t->p[k], &dt.f[k]));
+		P += t->p[k];
+	}
+	HIP_OK(h, buf.up(t->n_inst, B, &dt.n_inst));
+	HIP_OK(h, buf.up(t->m_inst, B * L, &dt.m_inst));
+	HIP_OK(h, buf.up(t->p_inst, B * L, &dt.p_inst));
+	hoqp_result_batch d;
+	std::memset(&d, 0, sizeof(d));
+	HIP_OK(h, buf.out(o->x, B * n, &d.x));
+	HIP_OK(h, buf.out(o->x_levels, B * L * n, &d.x_levels));
+	HIP_OK(h, buf.out(o->v, B * P, &d.v));
+	HIP_OK(h, buf.out(o->level_res, B * L, &d.level_res));
+	HIP_OK(h, buf.out(o->Z_levels, B * L * n * n, &d.Z_levels));
+	HIP_OK(h, buf.out(o->nz_levels, B * L, &d.nz_levels));
+	HIP_OK(h, buf.out(o->iters, B * L, &d.iters));
+	HIP_OK(h, buf.out(o->status, B, &d.status));
+	HIP_OK(h, buf.out(o->flags, B * L, &d.flags));
+	HIP_OK(h, buf.out(o->eq_res_max, B * L, &d.eq_res_max));
+	HIP_OK(h, buf.out(o->ineq_viol_max, B * L, &d.ineq_viol_max));
+	HIP_OK(h, buf.out(o->active_mask, B, &d.active_mask));
+	int rc = hoqp_solve_tasks_batched(h, &dt, &d, nullptr);
+	if (rc)
+		return rc;
+	HIP_OK(h, hipStreamSynchronize(nullptr));
+	HIP_OK(h, down(o->x, d.x, B * n));
+	HIP_OK(h, down(o->x_levels, d.x_levels, B * L * n));
+	HIP_OK(h, down(o->v, d.v, B * P));
+	HIP_OK(h, down(o->level_res, d.level_res, B * L));
+	HIP_OK(h, down(o->Z_levels, d.Z_levels, B * L * n * n));
+	HIP_OK(h, down(o->nz_levels, d.nz_levels, B * L));
+	HIP_OK(h, down(o->iters, d.iters, B * L));
+	HIP_OK(h, down(o->status, d.status, B));
+	HIP_OK(h, down(o->flags, d.flags, B * L));
+	HIP_OK(h, down(o->eq_res_max, d.eq_res_max, B * L));
+	HIP_OK(h, down(o->ineq_viol_max, d.ineq_viol_max, B * L));
+	HIP_OK(h, down(o->active_mask, d.active_mask, B));
+	return 0;
+}
+
+extern "C" int hoqp_solve_wbc_host(hoqp_handle *h, const hoqp_wbc_inputs *in, const hoqp_wbc_outputs *o)
+{
+	if (!h)
+		return -1;
+	if (!in || !o)
+		return fail(h, -1, "null argument");
+	if (in->batch < 0)
+		return fail(h, -1, "negative batch");
+	HIP_OK(h, hipSetDevice(h->cfg.device));
+	DevBuf buf;
+	const size_t B = in->batch;
+	hoqp_wbc_inputs di = *in;
+	HIP_OK(h, buf.up(in->M, B * 324, &di.M));
+	HIP_OK(h, buf.up(in->h, B * 18, &di.h));
+	HIP_OK(h, buf.up(in->Jfoot, B * 216, &di.Jfoot));
+	HIP_OK(h, buf.up(in->Jdotu, B * 12, &di.Jdotu));
+	HIP_OK(h, buf.up(in->footpos, B * 12, &di.footpos));
+	HIP_OK(h, buf.up(in->Jb, B * 108, &di.Jb));
+	HIP_OK(h, buf.up(in->q, B * 19, &di.q));
+	HIP_OK(h, buf.up(in->u, B * 18, &di.u));
+	HIP_OK(h, buf.up(in->base_cmd, B * 9, &di.base_cmd));
+	HIP_OK(h, buf.up(in->leg_cmd, B * 36, &di.leg_cmd));
+	HIP_OK(h, buf.up(in->contact, B * 4, &di.contact));
+	hoqp_wbc_outputs d;
+	std::memset(&d, 0, sizeof(d));
+	double *xtmp = nullptr;
+	HIP_OK(h, buf.out(o->x ? o->x : (double *)1, B * 30, &xtmp));
+	d.x = xtmp;
+	HIP_OK(h, buf.out(o->qdd, B * 12, &d.qdd));
+	HIP_OK(h, buf.out(o->tau, B * 12, &d.tau));
+	HIP_OK(h, buf.out(o->v, B * 40, &d.v));
+	HIP_OK(h, buf.out(o->flags, B * 5, &d.flags));
+	HIP_OK(h, buf.out(o->eq_res_max, B * 5, &d.eq_res_max));
+	HIP_OK(h, buf.out(o->ineq_viol_max, B * 5, &d.ineq_viol_max));
+	HIP_OK(h, buf.out(o->level_res, B * 5, &d.level_res));
+	HIP_OK(h, buf.out(o->active_mask, B, &d.active_mask));
+	HIP_OK(h, buf.out(o->status, B, &d.status));
+	HIP_OK(h, buf.out(o->iters, B * 5, &d.iters));
+	HIP_OK(h, buf.out(o->nz_levels, B * 5, &d.nz_levels));
+	HIP_OK(h, buf.out(o->x_levels, B * 150, &d.x_levels));
+	int rc = hoqp_solve_wbc_batched(h, &di, &d, nullptr);
+	if (rc)
+		return rc;
+	HIP_OK(h, hipStreamSynchronize(nullptr));
+	HIP_OK(h, down(o->x, (const double *)d.x, B * 30));
+	HIP_OK(h, down(o->qdd, (const double *)d.qdd, B * 12));
+	HIP_OK(h, down(o->tau, (const double *)d.tau, B * 12));
+	HIP_OK(h, down(o->v, (const double *)d.v, B * 40));
+	HIP_OK(h, down(o->flags, (const int *)d.flags, B * 5));
+	HIP_OK(h, down(o->eq_res_max, (const double *)d.eq_res_max, B * 5));
+	HIP_OK(h, down(o->ineq_viol_max, (const double *)d.ineq_viol_max, B * 5));
+	HIP_OK(h, down(o->level_res, (const double *)d.level_res, B * 5));
+	HIP_OK(h, down(o->active_mask, (const unsigned long long *)d.active_mask, B));
+	HIP_OK(h, down(o->status, (const int *)d.status, B));
+	HIP_OK(h, down(o->iters, (const int *)d.iters, B * 5));
+	HIP_OK(h, down(o->nz_levels, (const int *)d.nz_levels, B * 5));
+	HIP_OK(h, down(o->x_levels, (const double *)d.x_levels, B * 150));
+	return 0;
+}
+
 extern "C" int hoqp_synchronize(hoqp_handle *h, void *stream)
 {
 	if (!h)

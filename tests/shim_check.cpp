@@ -1,0 +1,108 @@
+// shim_check.cpp -- drives include/hoqp.hpp the way the reference drives its own classes
+// (ConstructOptProblems, ho_qp_controller.cpp:120-141; CalcJointCmd, :7-25).  Used by
+// tests/test_gpu_shim.py: reads a text fixture, prints results as text.
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+
+#include "hoqp.hpp"
+
+using hoqp::MatrixXd;
+using hoqp::VectorXd;
+
+static MatrixXd read_mat(std::istream &in, int r, int c)
+{
+	MatrixXd m(r, c);
+	for (int i = 0; i < r; ++i)
+		for (int j = 0; j < c; ++j) {
+			double v;
+			in >> v;
+			m(i, j) = v;
+		}
+	return m;
+}
+static VectorXd read_vec(std::istream &in, int n)
+{
+	VectorXd v(n);
+	for (int i = 0; i < n; ++i) {
+		double t;
+		in >> t;
+		v(i) = t;
+	}
+	return v;
+}
+static void print_vec(const char *name, const VectorXd &v)
+{
+	std::printf("%s %d", name, (int)v.rows());
+	for (int i = 0; i < v.rows(); ++i)
+		std::printf(" %.17g", v(i));
+	std::printf("\n");
+}
+
+int main(int argc, char **argv)
+{
+	if (argc < 2)
+		return 2;
+	std::ifstream in(argv[1]);
+	std::string kind;
+	int semantics;
+	in >> kind >> semantics;
+	hoqp_config cfg;
+	hoqp_default_config(&cfg);
+	cfg.semantics = semantics;
+	if (semantics == HOQP_SEMANTICS_PAPER)
+		cfg.eps = 0.0;
+	hoqp::configure(cfg);
+	if (kind == "tasks") {
+		int n, L;
+		in >> n >> L;
+		std::vector<TaskDefinition> tasks(L);
+		for (int k = 0; k < L; ++k) {
+			int m, p;
+			in >> m >> p;
+			if (m) {
+				tasks[k].A = read_mat(in, m, n);
+				tasks[k].b = read_vec(in, m);
+			}
+			if (p) {
+				tasks[k].D = read_mat(in, p, n);
+				tasks[k].f = read_vec(in, p);
+			}
+		}
+		// exactly ConstructOptProblems, ho_qp_controller.cpp:120-141
+		std::vector<std::shared_ptr<control::HoQpProblem>> opt_problems(tasks.size());
+		opt_problems[0] = std::shared_ptr<control::HoQpProblem>(new control::HoQpProblem(tasks[0]));
+		for (size_t i = 1; i < tasks.size(); ++i)
+			opt_problems[i] = std::shared_ptr<control::HoQpProblem>(
+				new control::HoQpProblem(tasks[i], opt_problems[i - 1]));
+		for (size_t i = 0; i < tasks.size(); ++i) {
+			std::printf("level %zu nz %d nslack %d status %d\n", i,
+				    (int)opt_problems[i]->GetStackedNullspaceMatrix().cols(),
+				    opt_problems[i]->GetStackedNumSlackVars(), opt_problems[i]->GetStatus());
+			print_vec("x", opt_problems[i]->GetSolution());
+			print_vec("v", opt_problems[i]->GetStackedSlackSolutions());
+		}
+		TaskDefinition st = opt_problems.back()->GetStackedTasks();
+		std::printf("stacked %d %d\n", (int)st.A.rows(), (int)st.D.rows());
+	} else {
+		std::vector<double> M(324), h(18), Jf(216), Jdu(12), fp(12), Jb(108);
+		for (auto *v : {&M, &h, &Jf, &Jdu, &fp, &Jb})
+			for (auto &e : *v)
+				in >> e;
+		VectorXd q = read_vec(in, 19), u = read_vec(in, 18);
+		VectorXd bc = read_vec(in, 3), bd = read_vec(in, 3), bdd = read_vec(in, 3);
+		VectorXd lc = read_vec(in, 12), ld = read_vec(in, 12), ldd = read_vec(in, 12), cp = read_vec(in, 4);
+		control::HoQpController ctl;
+		ctl.SetModelDynamics(M.data(), h.data(), Jf.data(), Jdu.data(), fp.data(), Jb.data());
+		ctl.SetBaseCmd(bc, bd, bdd);
+		ctl.SetLegCmd(lc, ld, ldd, cp);
+		ctl.CalcJointCmd(q, u);
+		print_vec("qdd", ctl.GetJointAccelerationCmd());
+		print_vec("tau", ctl.GetJointTorqueCmd());
+		print_vec("x", ctl.GetSolution());
+		const int *fl = ctl.GetSolutionValidFlags();
+		std::printf("flags %d %d %d %d %d status %d\n", fl[0], fl[1], fl[2], fl[3], fl[4], ctl.GetStatus());
+	}
+	return 0;
+}
