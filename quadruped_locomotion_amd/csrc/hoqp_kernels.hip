@@ -20,716 +20,9 @@
 
 #include "../../include/hoqp.h"
 #include "hoqp_device.hpp"
+#include "hoqp_solve.hpp"
 
 namespace hoqp {
-
-// ---------------------------------------------------------------------------
-// kernel arguments and LDS layout
-// ---------------------------------------------------------------------------
-struct SolveArgs {
-	int batch, n, L;
-	int m[HOQP_MAX_LEVELS], p[HOQP_MAX_LEVELS];
-	const double *A[HOQP_MAX_LEVELS], *b[HOQP_MAX_LEVELS], *D[HOQP_MAX_LEVELS], *f[HOQP_MAX_LEVELS];
-	const int *n_inst, *m_inst, *p_inst;
-	int gate_prior, slack_quirk, max_iter;
-	double eps;
-	hoqp_result_batch out;
-	int Ptot;   // storage extent of stacked inequality rows
-	int mmax;   // max_k m[k]
-	int ld;	    // odd leading dimension >= n for Z, G, T
-	int ncol;   // columns of the QR workspace T
-	int chunk;  // rows staged per pass
-};
-
-struct Lds {
-	double *Z, *x, *G, *g, *s, *c, *T, *S, *BL, *r0, *rho, *a0, *tau, *rdiag, *rhs, *chol, *tmp;
-	int *piv, *cpos, *W, *colrow, *lsrow;
-};
-
-__host__ __device__ inline size_t lds_layout(const SolveArgs &a, char *base, Lds *l)
-{
-	size_t off = 0;
-	auto take = [&](size_t bytes) {
-		char *p = base ? base + off : nullptr;
-		off += (bytes + 7) & ~size_t(7);
-		return p;
-	};
-	const int n = a.n, ld = a.ld, P = a.Ptot, mm = a.mmax;
-	double *Z = (double *)take(sizeof(double) * n * ld);
-	double *x = (double *)take(sizeof(double) * ld);
-	double *G = (double *)take(sizeof(double) * (P ? P : 1) * ld);
-	double *g = (double *)take(sizeof(double) * (P + 1));
-	double *s = (double *)take(sizeof(double) * (P + 1));
-	double *c = (double *)take(sizeof(double) * (P + 1));
-	double *T = (double *)take(sizeof(double) * ld * a.ncol);
-	double *S = (double *)take(sizeof(double) * a.chunk * n);
-	double *BL = (double *)take(sizeof(double) * (mm ? mm : 1) * ld);
-	double *r0 = (double *)take(sizeof(double) * (mm + 1));
-	double *rho = (double *)take(sizeof(double) * (mm + 1));
-	double *a0 = (double *)take(sizeof(double) * (mm + 1));
-	double *tau = (double *)take(sizeof(double) * ld);
-	double *rdiag = (double *)take(sizeof(double) * ld);
-	double *rhs = (double *)take(sizeof(double) * a.ncol);
-	double *chol = (double *)take(sizeof(double) * ld * ld);
-	double *tmp = (double *)take(sizeof(double) * 2 * kWave);
-	int *piv = (int *)take(sizeof(int) * ld);
-	int *cpos = (int *)take(sizeof(int) * a.ncol);
-	int *W = (int *)take(sizeof(int) * ld);
-	int *colrow = (int *)take(sizeof(int) * a.ncol);
-	int *lsrow = (int *)take(sizeof(int) * (mm + 1));
-	if (l) {
-		*l = Lds{Z, x, G, g, s, c, T, S, BL, r0, rho, a0, tau, rdiag, rhs, chol, tmp, piv, cpos, W, colrow, lsrow};
-	}
-	return off;
-}
-
-// ---------------------------------------------------------------------------
-// staging and projection:  rows of A or D (global, [rows][nstore]) -> LDS S ([rows][n])
-// ---------------------------------------------------------------------------
-__device__ inline void stage_rows(const double *src, int rows, int nstore, int n, double *S)
-{
-	const int total = rows * nstore;
-	for (int idx = lane_id(); idx < total; idx += kWave) {
-		int r = idx / nstore, l = idx - r * nstore;
-		if (l < n)
-			S[r * n + l] = src[idx];
-	}
-	__syncthreads();
-}
-
-// out(r, j) = sum_l S[r][l] Z[l][j]  for r < rows, j < nz.  colmajor: out[j + (r0+r)*ldo]
-// (a column of T per row), else out[(r0+r)*ldo + j] (a row of G per row).
-__device__ inline void project_rows(const double *S, int rows, int n, const double *Z, int ldz, int nz, double *out,
-				    int ldo, int r0, bool colmajor)
-{
-	const int total = rows * nz;
-	for (int idx = lane_id(); idx < total; idx += kWave) {
-		int r = idx / nz, j = idx - r * nz;
-		const double *sr = S + r * n;
-		double acc = 0.0;
-		for (int l = 0; l < n; ++l)
-			acc = fma(sr[l], Z[l * ldz + j], acc);
-		if (colmajor)
-			out[(size_t)(r0 + r) * ldo + j] = acc;
-		else
-			out[(size_t)(r0 + r) * ldo + j] = acc;
-	}
-}
-
-// rhs[r0 + r] = sgn * (v[r] - S[r] . x)
-__device__ inline void residual_rows(const double *S, int rows, int n, const double *x, const double *v, double *out,
-				     int r0)
-{
-	for (int r = lane_id(); r < rows; r += kWave) {
-		const double *sr = S + r * n;
-		double acc = v[r];
-		for (int l = 0; l < n; ++l)
-			acc = fma(-sr[l], x[l], acc);
-		out[r0 + r] = acc;
-	}
-}
-
-// ---------------------------------------------------------------------------
-// least-squares solve on a finished factorization.
-// The B block of T holds, in pivot positions [k1, k2), the factor R_B (rb = k2-k1 rows)
-// of the nb "B" columns listed in bcols[0..nb): columns with k1 <= cpos < k2 are pivoted,
-// the rest (cpos < 0) are dependent/overdetermined.  Solves min |R_B' q - rhs| (rhs per B
-// column, indexed like bcols) and returns q_j in lane j (j < rb).  If eps > 0 the result
-// is corrected to first order for the reference's eps*I Tikhonov term.
-// ---------------------------------------------------------------------------
-__device__ inline double ls_solve(const double *T, int ldt, const int *piv, const int *cpos, const double *rdiag,
-				  int k1, int k2, int cb, int ce, const double *rhs, double *chol, int ldc,
-				  double *tmp, double eps)
-{
-	const int lane = lane_id();
-	const int rb = k2 - k1;
-	if (rb <= 0)
-		return 0.0;
-	// is any B column unpivoted?
-	int unp = 0;
-	for (int c = cb + lane; c < ce; c += kWave)
-		unp |= (cpos[c] < 0);
-	const bool square = (__ballot(unp) == 0ull);
-	double q = 0.0;
-	if (square && eps == 0.0) {
-		// forward substitution R_B' q = rhs, column oriented; lane j owns position k1 + j
-		double acc = (lane < rb) ? rhs[piv[k1 + lane]] : 0.0;
-		const double *mycol = (lane < rb) ? T + (size_t)piv[k1 + lane] * ldt : T;
-		for (int i = 0; i < rb; ++i) {
-			double qi = readlane_d(acc, i) / rdiag[k1 + i];
-			if (lane == i)
-				q = qi;
-			if (lane > i && lane < rb)
-				acc = fma(-mycol[k1 + i], qi, acc);
-		}
-		return q;
-	}
-	// corrected semi-normal equations:  S = R_B R_B',  S q = R_B rhs, one refinement step
-	auto rb_entry = [&](int i, int c) -> double {  // R_B(i, column c), i in [0, rb)
-		int cp = cpos[c];
-		if (cp >= k1 && cp < k2) {
-			int j = cp - k1;
-			return (i < j) ? T[(size_t)c * ldt + k1 + i] : (i == j ? rdiag[cp] : 0.0);
-		}
-		return (cp < 0) ? T[(size_t)c * ldt + k1 + i] : 0.0;
-	};
-	for (int idx = lane; idx < rb * rb; idx += kWave) {
-		int i = idx / rb, j = idx - i * rb;
-		double acc = 0.0;
-		for (int c = cb; c < ce; ++c)
-			acc = fma(rb_entry(i, c), rb_entry(j, c), acc);
-		chol[i * ldc + j] = acc;
-	}
-	__syncthreads();
-	// Cholesky (lower, in place), lane per row
-	for (int k = 0; k < rb; ++k) {
-		double d = sqrt(chol[k * ldc + k]);
-		__syncthreads();
-		if (lane > k && lane < rb)
-			chol[lane * ldc + k] /= d;
-		if (lane == k)
-			chol[k * ldc + k] = d;
-		__syncthreads();
-		if (lane > k && lane < rb) {
-			double lik = chol[lane * ldc + k];
-			for (int j = k + 1; j <= lane; ++j)
-				chol[lane * ldc + j] = fma(-lik, chol[j * ldc + k], chol[lane * ldc + j]);
-		}
-		__syncthreads();
-	}
-	auto chol_solve = [&](double t) -> double {  // lane j holds t_j, returns (L L')^-1 t in lane j
-		double acc = t, y = 0.0;
-		for (int i = 0; i < rb; ++i) {
-			double yi = readlane_d(acc, i) / chol[i * ldc + i];
-			if (lane == i)
-				y = yi;
-			if (lane > i && lane < rb)
-				acc = fma(-chol[lane * ldc + i], yi, acc);
-		}
-		acc = y;
-		double z = 0.0;
-		for (int i = rb - 1; i >= 0; --i) {
-			double zi = readlane_d(acc, i) / chol[i * ldc + i];
-			if (lane == i)
-				z = zi;
-			if (lane < i)
-				acc = fma(-chol[i * ldc + lane], zi, acc);
-		}
-		return z;
-	};
-	// t = R_B rhs
-	double t = 0.0;
-	if (lane < rb)
-		for (int c = cb; c < ce; ++c)
-			t = fma(rb_entry(lane, c), rhs[c], t);
-	q = chol_solve(t);
-	// refinement: res = rhs - R_B' q ; dq = S^-1 R_B res
-	if (lane < rb)
-		tmp[lane] = q;
-	__syncthreads();
-	double t2 = 0.0;
-	if (lane < rb) {
-		for (int c = cb; c < ce; ++c) {
-			double res = rhs[c];
-			for (int i = 0; i < rb; ++i)
-				res = fma(-rb_entry(i, c), tmp[i], res);
-			t2 = fma(rb_entry(lane, c), res, t2);
-		}
-	}
-	q += chol_solve(t2);
-	if (eps != 0.0)
-		q -= eps * chol_solve(q);
-	__syncthreads();
-	return (lane < rb) ? q : 0.0;
-}
-
-// ---------------------------------------------------------------------------
-// the per-level solve
-// ---------------------------------------------------------------------------
-struct LevelState {
-	int n, nz, P;  // decision vars, current null-space dimension, inequality rows stored
-	int status;
-};
-
-// Equality-constrained least-squares step of the active-set method, from scratch:
-//   min |B (y+p) - ...|  s.t.  G_W p = 0, minimum norm.  Columns of T: [W rows | LS rows | V rows].
-// Returns p_i in lane i; k1 = rank of the working set (reflectors [0,k1) stay valid in T).
-__device__ inline double eqp_step(const SolveArgs &a, const Lds &l, int nz, int rank, int mrows, int w,
-				  unsigned long long vmask, int nsoft0, int *k1_out, bool *overflow)
-{
-	const int lane = lane_id();
-	const int ld = a.ld;
-	const int nV = __popcll(vmask);
-	const int nb = mrows + nV;
-	const int ncol = w + nb;
-	*k1_out = 0;
-	if (ncol > a.ncol) {
-		*overflow = true;
-		return 0.0;
-	}
-	// column -> source row map
-	for (int c = lane; c < ncol; c += kWave) {
-		int src;
-		if (c < w)
-			src = l.W[c];  // G row
-		else if (c < w + mrows)
-			src = -1 - (c - w);  // LS row j
-		else {
-			// (c - w - mrows)-th set bit of vmask
-			int t = c - w - mrows;
-			unsigned long long mk = vmask;
-			for (int q = 0; q < t; ++q)
-				mk &= mk - 1;
-			src = __ffsll((long long)mk) - 1;
-		}
-		l.colrow[c] = src;
-		l.cpos[c] = -1;
-	}
-	__syncthreads();
-	for (int c = lane; c < ncol; c += kWave) {
-		int src = l.colrow[c];
-		double *col = l.T + (size_t)c * ld;
-		if (src >= 0) {
-			const double *row = l.G + (size_t)src * ld;
-			for (int i = 0; i < nz; ++i)
-				col[i] = row[i];
-			l.rhs[c] = (c < w) ? 0.0 : -l.s[src];
-		} else {
-			int j = -1 - src;
-			const double *row = l.BL + (size_t)j * ld;
-			for (int i = 0; i < nz; ++i)
-				col[i] = (i < rank) ? row[i] : 0.0;
-			l.rhs[c] = -l.rho[j];
-		}
-	}
-	__syncthreads();
-	(void)nsoft0;
-	int k1 = hh_factor(l.T, ld, nz, 0, 0, w, ncol, 1e-12, l.cpos, l.piv, l.tau, l.rdiag);
-	int k2 = hh_factor(l.T, ld, nz, k1, w, ncol, ncol, 1e-11, l.cpos, l.piv, l.tau, l.rdiag);
-	*k1_out = k1;
-	double q = ls_solve(l.T, ld, l.piv, l.cpos, l.rdiag, k1, k2, w, ncol, l.rhs, l.chol, ld, l.tmp, 0.0);
-	// u = [0 (k1) ; q ; 0],  p = Q u
-	double u = 0.0;
-	{
-		// move q from lane j to lane k1 + j
-		int srcl = lane - k1;
-		double qq = __shfl(q, srcl < 0 ? 0 : srcl);
-		u = (srcl >= 0 && srcl < k2 - k1) ? qq : 0.0;
-	}
-	return hh_apply_vec(u, nz, l.T, ld, l.piv, l.tau, 0, k2, false);
-}
-
-__device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState &st, int inst, int k, int m, int p)
-{
-	const int lane = lane_id();
-	const int n = st.n, ld = a.ld;
-	const int nz = st.nz, P = st.P;
-	const int nstore = a.n;
-	const bool consider = (nz > 0) && (a.gate_prior ? (p > 0) : (p > 0 || P > 0));
-	int iters = 0;
-
-	// ---- 1. project the task into the current null space (ConstructHMatrix/CVector/
-	//         DMatrix/FVector of ho_qp_problem.cpp:180-285, in factored form) ----
-	for (int c = lane; c < a.ncol; c += kWave)
-		l.cpos[c] = -1;
-	for (int r0 = 0; r0 < m; r0 += a.chunk) {
-		int rows = min(a.chunk, m - r0);
-		stage_rows(a.A[k] + ((size_t)inst * a.m[k] + r0) * nstore, rows, nstore, n, l.S);
-		project_rows(l.S, rows, n, l.Z, ld, nz, l.T, ld, r0, true);
-		residual_rows(l.S, rows, n, l.x, a.b[k] + (size_t)inst * a.m[k] + r0, l.rhs, r0);
-		__syncthreads();
-	}
-	for (int r0 = 0; r0 < p; r0 += a.chunk) {
-		int rows = min(a.chunk, p - r0);
-		stage_rows(a.D[k] + ((size_t)inst * a.p[k] + r0) * nstore, rows, nstore, n, l.S);
-		project_rows(l.S, rows, n, l.Z, ld, nz, l.G, ld, P + r0, false);
-		residual_rows(l.S, rows, n, l.x, a.f[k] + (size_t)inst * a.p[k] + r0, l.g, P + r0);
-		__syncthreads();
-	}
-	const int Pn = P + p;
-
-	// ---- 2. complete orthogonal decomposition of A Z (CalcNullSpaceProjMatrix, math.hpp:99-104,
-	//         with an orthonormal Householder basis instead of the FullPivLU kernel) ----
-	int rank = 0;
-	if (m > 0 && nz > 0)
-		rank = hh_factor(l.T, ld, nz, 0, 0, m, m, kEpsMach * (double)max(m, nz), l.cpos, l.piv, l.tau, l.rdiag);
-
-	// ---- 3. rotate Z and every stored inequality row: Z <- Z Q, G <- G Q ----
-	if (rank > 0) {
-		hh_apply_right_rows(l.Z, ld, n, nz, l.T, ld, l.piv, l.tau, 0, rank);
-		hh_apply_right_rows(l.G, ld, Pn, nz, l.T, ld, l.piv, l.tau, 0, rank);
-	}
-	__syncthreads();
-
-	// LS rows in rotated coordinates: BL[j][0..rank) for j < m (pivoted rows first), r0 likewise
-	double yi = 0.0;  // lane i holds y_i
-	if (m > 0) {
-		// row order: pivot positions 0..rank-1, then unpivoted columns in index order
-		if (lane == 0) {
-			int t = rank;
-			for (int c = 0; c < m; ++c)
-				if (l.cpos[c] < 0)
-					l.lsrow[t++] = c;
-			for (int j = 0; j < rank; ++j)
-				l.lsrow[j] = l.piv[j];
-		}
-		__syncthreads();
-		for (int j = lane; j < m; j += kWave) {
-			int c = l.lsrow[j];
-			double *row = l.BL + (size_t)j * ld;
-			for (int i = 0; i < rank; ++i) {
-				double v;
-				if (j < rank)
-					v = (i < j) ? l.T[(size_t)c * ld + i] : (i == j ? l.rdiag[j] : 0.0);
-				else
-					v = l.T[(size_t)c * ld + i];
-				row[i] = v;
-			}
-			l.r0[j] = l.rhs[c];
-		}
-		__syncthreads();
-	}
-
-	if (!consider) {
-		// ---- 4a. unconstrained level: y1 = argmin |R' y1 - r0| (+ eps term), y2 = 0 ----
-		if (rank > 0) {
-			double q = ls_solve(l.T, ld, l.piv, l.cpos, l.rdiag, 0, rank, 0, m, l.rhs, l.chol, ld, l.tmp, a.eps);
-			yi = q;
-		}
-	} else {
-		// ---- 4b. primal active set on the piecewise quadratic ----
-		// s_i = G_i y - g_i (all rows), rho_j = B0_j y - r0_j
-		for (int i = lane; i < Pn; i += kWave)
-			l.s[i] = -l.g[i];
-		for (int j = lane; j < m; j += kWave)
-			l.rho[j] = -l.r0[j];
-		__syncthreads();
-		const unsigned long long softmask = (p >= 64) ? ~0ull : (((1ull << p) - 1ull) << P);
-		const unsigned long long hardmask = (P >= 64) ? ~0ull : ((1ull << P) - 1ull);
-		unsigned long long wmask = 0ull;
-		int w = 0;
-		// rows that start violated although they are hard: flag (no phase 1 here)
-		{
-			int bad = 0;
-			if (lane < P)
-				bad = l.s[lane] > 1e-9 * (1.0 + fabs(l.g[lane]));
-			if (__ballot(bad))
-				st.status |= HOQP_STATUS_INFEASIBLE_START;
-		}
-		bool done = false;
-		for (iters = 0; iters < a.max_iter && !done; ++iters) {
-			// violated soft rows
-			int isV = 0;
-			if (lane < Pn && ((softmask >> lane) & 1ull))
-				isV = l.s[lane] > 1e-11 * (1.0 + fabs(l.g[lane]));
-			const unsigned long long vmask = __ballot(isV);
-			int k1 = 0;
-			bool overflow = false;
-			double pi = eqp_step(a, l, nz, rank, m, w, vmask, P, &k1, &overflow);
-			if (overflow) {
-				st.status |= HOQP_STATUS_WORKSPACE;
-				break;
-			}
-			double pn = wave_max(fabs(pi));
-			double yn = wave_max(fabs(yi));
-			if (!(pn > 1e-10 * (1.0 + yn))) {
-				if (w == 0) {
-					done = true;
-					break;
-				}
-				// multipliers: G_W' mu = -grad,  grad = B0' rho + G_V' s_V
-				double gi = 0.0;
-				if (lane < nz) {
-					if (lane < rank)
-						for (int j = 0; j < m; ++j)
-							gi = fma(l.BL[(size_t)j * ld + lane], l.rho[j], gi);
-					unsigned long long mk = vmask;
-					while (mk) {
-						int r = __ffsll((long long)mk) - 1;
-						mk &= mk - 1;
-						gi = fma(l.G[(size_t)r * ld + lane], l.s[r], gi);
-					}
-				}
-				double gn = wave_max(fabs(gi));
-				double ti = hh_apply_vec(-gi, nz, l.T, ld, l.piv, l.tau, 0, k1, true);
-				// back substitution R_C mu = t (k1 x k1, pivot positions)
-				double acc = ti, mu = 0.0;
-				for (int i = k1 - 1; i >= 0; --i) {
-					double mi = readlane_d(acc, i) / l.rdiag[i];
-					if (lane == i)
-						mu = mi;
-					if (lane < i)
-						acc = fma(-l.T[(size_t)l.piv[i] * ld + lane], mi, acc);
-				}
-				int wi = (lane < k1) ? l.piv[lane] : -1;  // column index == position in W
-				int drop;
-				double worst = wave_argmin((lane < k1) ? mu : 1e300, wi, &drop);
-				if (!(worst < -1e-9 * (1.0 + gn)) || drop < 0) {
-					done = true;
-					break;
-				}
-				wmask &= ~(1ull << l.W[drop]);
-				__syncthreads();
-				if (lane == 0)
-					for (int j = drop; j < w - 1; ++j)
-						l.W[j] = l.W[j + 1];
-				--w;
-				__syncthreads();
-				continue;
-			}
-			// c_i = G_i p for every row, a0_j = B0_j p
-			if (lane < nz)
-				l.tmp[lane] = pi;
-			__syncthreads();
-			double ci = 0.0, si = 0.0;
-			if (lane < Pn) {
-				const double *row = l.G + (size_t)lane * ld;
-				for (int i = 0; i < nz; ++i)
-					ci = fma(row[i], l.tmp[i], ci);
-				si = l.s[lane];
-				l.c[lane] = ci;
-			}
-			double a0 = 0.0, rj = 0.0;
-			if (lane < m) {
-				const double *row = l.BL + (size_t)lane * ld;
-				for (int i = 0; i < rank; ++i)
-					a0 = fma(row[i], l.tmp[i], a0);
-				rj = l.rho[lane];
-			}
-			__syncthreads();
-			const double q0 = wave_sum(a0 * rj), q1 = wave_sum(a0 * a0);
-			// ratio test on hard rows outside the working set
-			const bool isHard = lane < P && ((hardmask >> lane) & 1ull) && !((wmask >> lane) & 1ull);
-			double ah = 1e300;
-			if (isHard && ci > 1e-12 * pn)
-				ah = fmax(0.0, -si / ci);
-			int blk;
-			double t_hard = wave_argmin(ah, lane, &blk);
-			if (!(t_hard < 1e299))
-				blk = -1;
-			// exact line search on the piecewise quadratic along p
-			const bool isSoft = lane < Pn && ((softmask >> lane) & 1ull);
-			const double tolv = 1e-11 * (1.0 + fabs(isSoft ? l.g[lane] : 0.0));
-			double tb = 1e300;
-			if (isSoft && ci != 0.0 && ((si > tolv && ci < 0.0) || (si <= tolv && ci > 0.0))) {
-				double t = -si / ci;
-				if (t > 0.0)
-					tb = t;
-			}
-			auto dphi = [&](double t) -> double {  // uniform t: lanes add their own row
-				double sv = si + t * ci;
-				double mine = (isSoft && sv > 0.0) ? ci * sv : 0.0;
-				return q0 + q1 * t + wave_sum(mine);
-			};
-			// each lane evaluates d(phi)/dt at its own breakpoint (rows read from LDS)
-			double dmine = -1.0;
-			if (tb < 1e299) {
-				double acc = q0 + q1 * tb;
-				unsigned long long mk = softmask;
-				while (mk) {
-					int r = __ffsll((long long)mk) - 1;
-					mk &= mk - 1;
-					double cr = l.c[r];
-					double sv = l.s[r] + tb * cr;
-					if (sv > 0.0 && r != lane)
-						acc = fma(cr, sv, acc);
-				}
-				dmine = acc;
-			}
-			double t_hi = wave_min((tb < 1e299 && dmine >= 0.0) ? tb : 1e300);
-			double t_lo = wave_max((tb < t_hi) ? tb : 0.0);
-			double tm = (t_hi < 1e299) ? 0.5 * (t_lo + t_hi) : t_lo + 1.0;
-			double slope;
-			{
-				double sv = si + tm * ci;
-				slope = q1 + wave_sum((isSoft && sv > 0.0) ? ci * ci : 0.0);
-			}
-			double d_lo = dphi(t_lo);
-			double t_star;
-			if (d_lo >= 0.0)
-				t_star = t_lo;
-			else if (slope > 0.0)
-				t_star = fmin(t_lo - d_lo / slope, t_hi);
-			else
-				t_star = (t_hi < 1e299) ? t_hi : t_lo;
-			double t = fmin(t_star, t_hard);
-			yi = fma(t, pi, yi);
-			if (lane < Pn)
-				l.s[lane] = fma(t, ci, si);
-			if (lane < m)
-				l.rho[lane] = fma(t, a0, rj);
-			if (t_hard <= t_star && blk >= 0) {
-				if (w < ld) {
-					if (lane == 0)
-						l.W[w] = blk;
-					wmask |= 1ull << blk;
-					++w;
-				} else {
-					st.status |= HOQP_STATUS_WORKSPACE;
-					break;
-				}
-			}
-			__syncthreads();
-		}
-		if (!done)
-			st.status |= HOQP_STATUS_MAX_ITER;
-	}
-
-	// ---- 5. x_k = x_{k-1} + (Z Q) y  (GetSolution, ho_qp_problem.cpp:46-51); slack bookkeeping ----
-	__syncthreads();
-	if (lane < ld)
-		l.tmp[lane] = (lane < nz) ? yi : 0.0;
-	__syncthreads();
-	if (lane < n) {
-		const double *row = l.Z + (size_t)lane * ld;
-		double acc = l.x[lane];
-		for (int i = 0; i < nz; ++i)
-			acc = fma(row[i], l.tmp[i], acc);
-		l.x[lane] = acc;
-	}
-	if (lane < Pn) {
-		const double *row = l.G + (size_t)lane * ld;
-		double gi = l.g[lane];
-		for (int i = 0; i < nz; ++i)
-			gi = fma(-row[i], l.tmp[i], gi);
-		if (lane >= P) {
-			// v* = (D x - f)_+ ; the row becomes hard with rhs f + v* - D x  (ConstructFVector, :207-229)
-			double v = fmax(0.0, -gi);
-			if (a.out.v)
-				a.out.v[(size_t)inst * a.Ptot + lane] = v;
-			gi = fmax(gi, 0.0);
-		}
-		l.g[lane] = gi;
-	}
-	// level residual |A_k x_k - b_k| = |B0 y - r0|
-	{
-		double rj = 0.0;
-		if (lane < m) {
-			const double *row = l.BL + (size_t)lane * ld;
-			double acc = -l.r0[lane];
-			for (int i = 0; i < rank; ++i)
-				acc = fma(row[i], l.tmp[i], acc);
-			rj = acc;
-		}
-		double rn = sqrt(wave_sum(rj * rj));
-		if (lane == 0) {
-			if (a.out.level_res)
-				a.out.level_res[(size_t)inst * a.L + k] = rn;
-			if (a.out.iters)
-				a.out.iters[(size_t)inst * a.L + k] = iters;
-			if (a.out.nz_levels)
-				a.out.nz_levels[(size_t)inst * a.L + k] = nz - rank;
-		}
-	}
-	__syncthreads();
-
-	// ---- 6. Z_k = Z_{k-1} Q2, G <- G Q2 : drop the first `rank` rotated coordinates ----
-	if (rank > 0) {
-		for (int r = lane; r < n + Pn; r += kWave) {
-			double *row = (r < n) ? l.Z + (size_t)r * ld : l.G + (size_t)(r - n) * ld;
-			for (int i = rank; i < nz; ++i)
-				row[i - rank] = row[i];
-		}
-	}
-	st.nz = nz - rank;
-	st.P = Pn;
-	__syncthreads();
-
-	if (a.out.x_levels && lane < a.n)
-		a.out.x_levels[((size_t)inst * a.L + k) * a.n + lane] = (lane < n) ? l.x[lane] : 0.0;
-	if (a.out.Z_levels) {
-		double *Zo = a.out.Z_levels + ((size_t)inst * a.L + k) * a.n * a.n;
-		for (int idx = lane; idx < a.n * a.n; idx += kWave) {
-			int r = idx / a.n, c = idx - r * a.n;
-			Zo[idx] = (r < n && c < st.nz) ? l.Z[(size_t)r * ld + c] : 0.0;
-		}
-	}
-}
-
-__global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
-{
-	extern __shared__ __align__(16) char smem[];
-	Lds l;
-	lds_layout(a, smem, &l);
-	const int lane = lane_id();
-	const int inst = blockIdx.x;
-	if (inst >= a.batch)
-		return;
-	LevelState st;
-	st.n = a.n_inst ? a.n_inst[inst] : a.n;
-	st.nz = st.n;
-	st.P = 0;
-	st.status = 0;
-	const int n = st.n, ld = a.ld;
-	// InitPrevProblemValuesToDefault, ho_qp_problem.cpp:119-128:  Z = I, x = 0
-	for (int idx = lane; idx < n * ld; idx += kWave) {
-		int r = idx / ld, c = idx - r * ld;
-		l.Z[idx] = (r == c) ? 1.0 : 0.0;
-	}
-	if (lane < ld)
-		l.x[lane] = 0.0;
-	if (a.out.v)
-		for (int i = lane; i < a.Ptot; i += kWave)
-			a.out.v[(size_t)inst * a.Ptot + i] = 0.0;
-	__syncthreads();
-
-	for (int k = 0; k < a.L; ++k) {
-		int m = a.m_inst ? a.m_inst[(size_t)inst * a.L + k] : a.m[k];
-		int p = a.p_inst ? a.p_inst[(size_t)inst * a.L + k] : a.p[k];
-		solve_level(a, l, st, inst, k, m, p);
-	}
-
-	// ---- final x and the CheckSolutionValid flags (helper_functions.hpp:63-91) ----
-	double xi = (lane < n) ? l.x[lane] : 0.0;
-	if (__ballot(!isfinite(xi)))
-		st.status |= HOQP_STATUS_NONFINITE;
-	if (a.out.x && lane < a.n)
-		a.out.x[(size_t)inst * a.n + lane] = xi;
-	if (a.out.flags || a.out.eq_res_max || a.out.ineq_viol_max || a.out.active_mask) {
-		unsigned long long amask = 0ull;
-		int prow = 0;
-		for (int k = 0; k < a.L; ++k) {
-			int m = a.m_inst ? a.m_inst[(size_t)inst * a.L + k] : a.m[k];
-			int p = a.p_inst ? a.p_inst[(size_t)inst * a.L + k] : a.p[k];
-			double er = 0.0, iv = -1e300;
-			for (int r0 = 0; r0 < m; r0 += a.chunk) {
-				int rows = min(a.chunk, m - r0);
-				stage_rows(a.A[k] + ((size_t)inst * a.m[k] + r0) * a.n, rows, a.n, n, l.S);
-				residual_rows(l.S, rows, n, l.x, a.b[k] + (size_t)inst * a.m[k] + r0, l.rhs, 0);
-				__syncthreads();
-				double e = (lane < rows) ? fabs(l.rhs[lane]) : 0.0;
-				er = fmax(er, wave_max(e));
-				__syncthreads();
-			}
-			for (int r0 = 0; r0 < p; r0 += a.chunk) {
-				int rows = min(a.chunk, p - r0);
-				stage_rows(a.D[k] + ((size_t)inst * a.p[k] + r0) * a.n, rows, a.n, n, l.S);
-				residual_rows(l.S, rows, n, l.x, a.f[k] + (size_t)inst * a.p[k] + r0, l.rhs, 0);
-				__syncthreads();
-				double e = (lane < rows) ? -l.rhs[lane] : -1e300;  // D x - f
-				iv = fmax(iv, wave_max(e));
-				unsigned long long act = __ballot(lane < rows && e >= -1e-7);
-				if (prow + r0 < 64)
-					amask |= act << (prow + r0);
-				__syncthreads();
-			}
-			prow += p;
-			if (lane == 0) {
-				size_t o = (size_t)inst * a.L + k;
-				if (a.out.flags)
-					a.out.flags[o] = (!(er > 1e-7) && !(p > 0 && iv > 0.0)) ? 1 : 0;
-				if (a.out.eq_res_max)
-					a.out.eq_res_max[o] = er;
-				if (a.out.ineq_viol_max)
-					a.out.ineq_viol_max[o] = p ? iv : 0.0;
-			}
-		}
-		if (lane == 0 && a.out.active_mask)
-			a.out.active_mask[inst] = amask;
-	}
-	if (lane == 0 && a.out.status)
-		a.out.status[inst] = st.status;
-}
 
 // ---------------------------------------------------------------------------
 // WBC task construction (HoQpController::ConstructTasks, ho_qp_controller.cpp:147-184)
@@ -1092,8 +385,6 @@ static int fill_args(hoqp_handle *h, const hoqp_task_batch *t, const hoqp_result
 	a->Ptot = P;
 	a->mmax = mm;
 	a->ld = t->n | 1;
-	a->ncol = std::min(128, std::max(mm + P, 1));
-	a->chunk = 8;
 	return 0;
 }
 
@@ -1112,15 +403,13 @@ extern "C" size_t hoqp_lds_bytes(int n, int num_levels, const int *m, const int 
 	a.Ptot = P;
 	a.mmax = mm;
 	a.ld = n | 1;
-	a.ncol = std::min(128, std::max(mm + P, 1));
-	a.chunk = 8;
-	return lds_layout(a, nullptr, nullptr);
+	return (size_t)lds_offsets(a).total;
 }
 
 static int launch_solve(hoqp_handle *h, SolveArgs &a, hipStream_t s)
 {
 	a.ld = a.n | 1;
-	size_t lds = lds_layout(a, nullptr, nullptr);
+	size_t lds = (size_t)lds_offsets(a).total;
 	if ((int)lds > h->max_lds)
 		return fail(h, -5, "LDS workspace " + std::to_string(lds) + " B exceeds the device limit");
 	if (lds > 48 * 1024)
