@@ -14,6 +14,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -384,6 +385,21 @@ static int fill_args(hoqp_handle *h, const hoqp_task_batch *t, const hoqp_result
 	a->out = *out;
 	a->Ptot = P;
 	a->mmax = mm;
+	// which levels look at stored inequality rows, and does any of them also carry equality rows?
+	a->use_bl = 0;
+	a->last_ineq_use = -1;
+	{
+		int seen = 0;
+		for (int k = 0; k < t->num_levels; ++k) {
+			const bool looks = a->gate_prior ? (t->p[k] > 0) : (t->p[k] > 0 || seen > 0);
+			if (looks) {
+				a->last_ineq_use = k;
+				if (t->m[k] > 0)
+					a->use_bl = 1;
+			}
+			seen += t->p[k];
+		}
+	}
 	a->ld = t->n | 1;
 	return 0;
 }
@@ -403,11 +419,50 @@ extern "C" size_t hoqp_lds_bytes(int n, int num_levels, const int *m, const int 
 	a.Ptot = P;
 	a.mmax = mm;
 	a.ld = n | 1;
+	a.use_bl = 1;
 	return (size_t)lds_offsets(a).total;
 }
 
 static int launch_solve(hoqp_handle *h, SolveArgs &a, hipStream_t s)
 {
+#ifdef HOQP_PROFILE
+	// profiling build: per-section cycle stamps of one launch, printed to stderr
+	unsigned long long *dbg = nullptr;
+	if (getenv("HOQP_DBG") && a.batch > 0) {
+		HIP_OK(h, hipMalloc(&dbg, sizeof(unsigned long long) * 8 * a.batch));
+		HIP_OK(h, hipMemset(dbg, 0, sizeof(unsigned long long) * 8 * a.batch));
+	}
+	a.dbg = dbg;
+	struct Dump {
+		hoqp_handle *h;
+		unsigned long long *d;
+		int batch;
+		hipStream_t s;
+		~Dump()
+		{
+			if (!d)
+				return;
+			(void)hipStreamSynchronize(s);
+			std::vector<unsigned long long> host((size_t)8 * batch);
+			(void)hipMemcpy(host.data(), d, host.size() * 8, hipMemcpyDeviceToHost);
+			double sum[8] = {0};
+			for (int i = 0; i < batch; ++i)
+				for (int j = 0; j < 8; ++j)
+					sum[j] += (double)host[(size_t)i * 8 + j];
+			static const char *nm[8] = {"init", "project", "factor", "ls/bl", "rotate", "qp", "update", "tail"};
+			double tot = 0;
+			for (int j = 0; j < 8; ++j)
+				tot += sum[j];
+			fprintf(stderr, "[hoqp profile] memtime ticks (100 MHz) per instance:");
+			for (int j = 0; j < 8; ++j)
+				fprintf(stderr, " %s=%.0f", nm[j], sum[j] / batch);
+			fprintf(stderr, " total=%.0f\n", tot / batch);
+			(void)hipFree(d);
+		}
+	} dump{h, dbg, a.batch, s};
+#else
+	a.dbg = nullptr;
+#endif
 	a.ld = a.n | 1;
 	size_t lds = (size_t)lds_offsets(a).total;
 	if ((int)lds > h->max_lds)

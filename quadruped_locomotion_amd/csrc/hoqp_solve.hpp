@@ -17,7 +17,7 @@ namespace hoqp {
 constexpr int NR = 32;	  // register-array length, >= HOQP_MAX_VARS
 constexpr int LDV = 34;	  // leading dimension of the reflector store (even: 16-byte aligned rows)
 constexpr int SROW = 32;  // row stride of the task staging buffer
-constexpr int XROWS = 16; // dumped unpivoted columns (over-determined least squares)
+constexpr int XROWS = 16; // dumped unpivoted columns (over-determined least squares); aliases S
 constexpr int CHUNK = 8;  // task rows staged per pass
 
 static_assert(NR >= HOQP_MAX_VARS, "register arrays must cover n");
@@ -33,6 +33,9 @@ struct SolveArgs {
 	int Ptot;  // storage extent of stacked inequality rows (<= 64)
 	int mmax;  // max_k m[k] (<= 32)
 	int ld;	   // odd leading dimension >= n of Z, G, BL, X
+	int use_bl;	   // some level needs its equality rows inside the active-set loop
+	int last_ineq_use; // last level that looks at stored inequality rows (rows are dropped after it)
+	unsigned long long *dbg;  // HOQP_PROFILE builds only: [batch][8] cycle stamps per section
 };
 
 // byte offsets of the LDS arrays (shared by host sizing and device addressing)
@@ -58,14 +61,14 @@ __host__ __device__ inline LdsOff lds_offsets(const SolveArgs &a)
 	o.s = take(8 * (P + 1));
 	o.c = take(8 * (P + 1));
 	o.TV = take(8 * tv);
-	o.S = take(8 * CHUNK * SROW);
-	o.BL = take(8 * (mm ? mm : 1) * ld);
+	o.S = take(8 * ((CHUNK * SROW > XROWS * ld) ? CHUNK * SROW : XROWS * ld));
+	o.BL = take(8 * ((mm && a.use_bl) ? mm : 1) * ld);
 	o.r0 = take(8 * (mm + 1));
 	o.rho = take(8 * (mm + 1));
 	o.tau = take(8 * NR);
 	o.rdiag = take(8 * NR);
 	o.rhs = take(8 * kWave);
-	o.X = take(8 * XROWS * ld);
+	o.X = o.S;  // the staging buffer is dead whenever X is live
 	o.tmp = take(8 * kWave);
 	o.pivlane = take(4 * NR);
 	o.W = take(4 * NR);
@@ -107,6 +110,46 @@ __device__ inline Lds lds_bind(const SolveArgs &a, HOQP_LDS char *base)
 }
 
 // ---------------------------------------------------------------------------
+// Static-index row loops.  Register arrays may only be indexed by compile-time constants, but
+// the active row range [k, nr) is run-time (wave-uniform).  rows_from2 walks the rows in
+// blocks of 8 (pairs inside a block): blocks entirely outside [k, nr) are skipped by a scalar
+// branch, blocks entirely inside run unmasked, only the block containing k carries
+// per-element masks.  body(i, on0, on1) handles rows i, i+1; onX == false means "row < k".
+// ---------------------------------------------------------------------------
+template <typename Body>
+__device__ __forceinline__ void rows_from2(int k, int nr, Body body)
+{
+#pragma unroll
+	for (int b = 0; b < NR / 8; ++b) {
+		if (8 * b + 8 <= k || 8 * b >= nr)
+			continue;
+		if (8 * b >= k) {
+#pragma unroll
+			for (int j = 0; j < 8; j += 2)
+				body(8 * b + j, true, true);
+		} else {
+#pragma unroll
+			for (int j = 0; j < 8; j += 2)
+				body(8 * b + j, 8 * b + j >= k, 8 * b + j + 1 >= k);
+		}
+	}
+}
+
+// rows [0, nr) in pairs, whole blocks of 8 skipped beyond nr (entries in [nr, 8*ceil) must be benign)
+template <typename Body>
+__device__ __forceinline__ void rows_upto2(int nr, Body body)
+{
+#pragma unroll
+	for (int b = 0; b < NR / 8; ++b) {
+		if (8 * b >= nr)
+			continue;
+#pragma unroll
+		for (int j = 0; j < 8; j += 2)
+			body(8 * b + j);
+	}
+}
+
+// ---------------------------------------------------------------------------
 // Householder QR with column pivoting, ONE COLUMN PER LANE IN REGISTERS.
 //   col[0..nr)  : this lane's column (entries >= nr must be 0)
 //   mypos       : -1 = active (unpivoted) column, >= 0 = pivoted at that step, -2 = no column
@@ -125,13 +168,12 @@ __device__ inline int hh_factor_reg(double (&col)[NR], int &mypos, bool cand, in
 	double first = -1.0;
 	while (k < nr) {
 		double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-		for (int i = 0; i < NR; i += 2) {
-			double a = (i >= k) ? col[i] : 0.0;
-			double b = (i + 1 >= k) ? col[i + 1] : 0.0;
+		rows_from2(k, nr, [&](int i, bool on0, bool on1) {
+			const double a = on0 ? col[i] : 0.0;
+			const double b = on1 ? col[i + 1] : 0.0;
 			s0 = fma(a, a, s0);
 			s1 = fma(b, b, s1);
-		}
+		});
 		const bool mine = (mypos == -1) && cand;
 		int pc;
 		double best = wave_argmax(mine ? (s0 + s1) : -1.0, mine ? lane : -1, &pc);
@@ -144,9 +186,13 @@ __device__ inline int hh_factor_reg(double (&col)[NR], int &mypos, bool cand, in
 			break;
 		ldsd *vr = VR + k * LDV;
 		if (lane == pc) {
-#pragma unroll
-			for (int i = 0; i < NR; ++i)
-				vr[i] = col[i];
+			ldsd2 *w2 = (ldsd2 *)vr;
+			rows_upto2(nr, [&](int i) {
+				d2v t;
+				t.x = col[i];
+				t.y = col[i + 1];
+				w2[i >> 1] = t;
+			});
 			mypos = k;
 		}
 		__syncthreads();
@@ -157,22 +203,19 @@ __device__ inline int hh_factor_reg(double (&col)[NR], int &mypos, bool cand, in
 		if (mypos == -1) {
 			double vv[NR];
 			const ldsd2 *vr2 = (const ldsd2 *)vr;
-#pragma unroll
-			for (int i = 0; i < NR; i += 2) {
-				d2v t = vr2[i >> 1];
-				vv[i] = (i > k) ? t.x : (i == k ? v0 : 0.0);
-				vv[i + 1] = (i + 1 > k) ? t.y : (i + 1 == k ? v0 : 0.0);
-			}
 			double d0 = 0.0, d1 = 0.0;
-#pragma unroll
-			for (int i = 0; i < NR; i += 2) {
+			rows_from2(k, nr, [&](int i, bool on0, bool on1) {
+				const d2v t = vr2[i >> 1];
+				vv[i] = on0 ? ((i == k) ? v0 : t.x) : 0.0;
+				vv[i + 1] = on1 ? ((i + 1 == k) ? v0 : t.y) : 0.0;
 				d0 = fma(vv[i], col[i], d0);
 				d1 = fma(vv[i + 1], col[i + 1], d1);
-			}
+			});
 			const double d = (d0 + d1) * tk;
-#pragma unroll
-			for (int i = 0; i < NR; ++i)
+			rows_from2(k, nr, [&](int i, bool, bool) {
 				col[i] = fma(-d, vv[i], col[i]);
+				col[i + 1] = fma(-d, vv[i + 1], col[i + 1]);
+			});
 		}
 		if (lane == 0) {
 			vr[k] = v0;  // program order: after every lane's read of vr[k] above
@@ -201,22 +244,19 @@ __device__ inline void hh_apply_right_rows_reg(ldsd *A0, int n0, ldsd *A1, int n
 		for (int k = ka; k < kb; ++k) {
 			const ldsd2 *vr2 = (const ldsd2 *)(VR + k * LDV);
 			double vv[NR];
-#pragma unroll
-			for (int i = 0; i < NR; i += 2) {
-				d2v t = vr2[i >> 1];
-				vv[i] = (i >= k && i < nr) ? t.x : 0.0;
-				vv[i + 1] = (i + 1 >= k && i + 1 < nr) ? t.y : 0.0;
-			}
 			double d0 = 0.0, d1 = 0.0;
-#pragma unroll
-			for (int i = 0; i < NR; i += 2) {
+			rows_from2(k, nr, [&](int i, bool on0, bool on1) {
+				const d2v t = vr2[i >> 1];
+				vv[i] = on0 ? t.x : 0.0;
+				vv[i + 1] = on1 ? t.y : 0.0;
 				d0 = fma(vv[i], row[i], d0);
 				d1 = fma(vv[i + 1], row[i + 1], d1);
-			}
+			});
 			const double d = (d0 + d1) * l.tau[k];
-#pragma unroll
-			for (int i = 0; i < NR; ++i)
+			rows_from2(k, nr, [&](int i, bool, bool) {
 				row[i] = fma(-d, vv[i], row[i]);
+				row[i + 1] = fma(-d, vv[i + 1], row[i + 1]);
+			});
 		}
 #pragma unroll
 		for (int i = 0; i < NR; ++i)
@@ -503,9 +543,26 @@ __device__ inline void project_task(const double *__restrict__ rows_g, const dou
 	__syncthreads();
 }
 
+#ifdef HOQP_PROFILE
+#define HOQP_STAMP(slot)                                                              \
+	do {                                                                          \
+		unsigned long long now_ = __builtin_amdgcn_s_memtime();               \
+		if (a.dbg && lane_id() == 0)                                          \
+			a.dbg[(size_t)blockIdx.x * 8 + (slot)] += now_ - st.t_last;   \
+		st.t_last = __builtin_amdgcn_s_memtime();                             \
+	} while (0)
+#else
+#define HOQP_STAMP(slot) \
+	do {             \
+	} while (0)
+#endif
+
 struct LevelState {
-	int n, nz, P;
+	int n, nz;
+	int P;	   // live stored inequality rows
+	int Pout;  // inequality rows emitted so far (offset of this level's slacks in out.v)
 	int status;
+	unsigned long long t_last;
 };
 
 // ---------------------------------------------------------------------------
@@ -600,6 +657,9 @@ __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState 
 	const int nstore = a.n;
 	const int Pn = P + p;
 	const bool consider = (nz > 0) && (a.gate_prior ? (p > 0) : (p > 0 || P > 0));
+	// stored rows are still needed by a later level?  (else they are neither rotated nor kept)
+	const bool keep_rows = k < a.last_ineq_use;
+	const int Pg = (consider || keep_rows) ? Pn : 0;  // rows that take part in rotation / update
 	int iters = 0;
 	double level_res2 = 0.0;
 
@@ -621,6 +681,7 @@ __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState 
 				     nz, ld, zc, false, P, l);
 	}
 
+	HOQP_STAMP(1);
 	// ---- 2. complete orthogonal decomposition of A Z (CalcNullSpaceProjMatrix, math.hpp:99-104,
 	//         with an orthonormal Householder basis instead of the FullPivLU kernel) ----
 	int rank = 0;
@@ -638,6 +699,7 @@ __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState 
 		__syncthreads();  // every column is in registers before TV is reused as the reflector store
 		int mypos = has ? -1 : -2;
 		rank = hh_factor_reg(col, mypos, has, nz, 0, kEpsMach * (double)max(m, nz), l);
+		HOQP_STAMP(2);
 		const bool unp = has && mypos == -1;
 		const unsigned long long um = __ballot(unp);
 		const int nunp = __popcll(um);
@@ -682,9 +744,11 @@ __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState 
 			level_res2 = wave_sum(has ? rhs_c * rhs_c : 0.0);
 		}
 		__syncthreads();
+		HOQP_STAMP(3);
 		// ---- 3. rotate Z and every stored inequality row: Z <- Z Q, G <- G Q ----
 		if (rank > 0)
-			hh_apply_right_rows_reg(l.Z, n, l.G, Pn, ld, nz, 0, rank, l);
+			hh_apply_right_rows_reg(l.Z, n, l.G, Pg, ld, nz, 0, rank, l);
+		HOQP_STAMP(4);
 	} else if (m > 0) {
 		// no free directions left: the residual is what it is
 		double r = (lane < m) ? l.rhs[lane] : 0.0;
@@ -879,12 +943,13 @@ __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState 
 		}
 	}
 
+	HOQP_STAMP(5);
 	// ---- 5./6. x_k = x_{k-1} + (Z Q) y (GetSolution, ho_qp_problem.cpp:46-51); slack bookkeeping
 	//            (ConstructFVector, :207-229); Z_k = Z_{k-1} Q2, G <- G Q2 (:172-178) ----
 	__syncthreads();
 	l.tmp[lane] = (lane < nz) ? yi : 0.0;
 	__syncthreads();
-	for (int r = lane; r < n + Pn; r += kWave) {
+	for (int r = lane; r < n + Pg; r += kWave) {
 		const bool isZ = r < n;
 		ldsd *rowp = isZ ? l.Z + r * ld : l.G + (r - n) * ld;
 		double row[NR];
@@ -910,7 +975,7 @@ __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState 
 			if (gr >= P) {
 				// v* = (D x - f)_+ ; the row becomes hard with rhs f + v* - D x
 				if (a.out.v)
-					a.out.v[(size_t)inst * a.Ptot + gr] = fmax(0.0, -gi);
+					a.out.v[(size_t)inst * a.Ptot + st.Pout + (gr - P)] = fmax(0.0, -gi);
 				gi = fmax(gi, 0.0);
 			}
 			l.g[gr] = gi;
@@ -930,9 +995,13 @@ __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState 
 		if (a.out.nz_levels)
 			a.out.nz_levels[(size_t)inst * a.L + k] = nz - rank;
 	}
+	if (Pg == 0 && p > 0 && lane < p && a.out.v)  // no free direction left: v* = (D x - f)_+ as is
+		a.out.v[(size_t)inst * a.Ptot + st.Pout + lane] = fmax(0.0, -l.g[P + lane]);
 	st.nz = nz - rank;
-	st.P = Pn;
+	st.P = keep_rows ? Pn : 0;
+	st.Pout += p;
 	__syncthreads();
+	HOQP_STAMP(6);
 
 	if (a.out.x_levels && lane < a.n)
 		a.out.x_levels[((size_t)inst * a.L + k) * a.n + lane] = (lane < n) ? l.x[lane] : 0.0;
@@ -960,7 +1029,9 @@ __global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
 	st.n = a.n_inst ? a.n_inst[inst] : a.n;
 	st.nz = st.n;
 	st.P = 0;
+	st.Pout = 0;
 	st.status = 0;
+	st.t_last = __builtin_amdgcn_s_memtime();
 	const int n = st.n, ld = a.ld;
 	// InitPrevProblemValuesToDefault, ho_qp_problem.cpp:119-128:  Z = I, x = 0
 	for (int idx = lane; idx < n * ld; idx += kWave) {
@@ -974,6 +1045,7 @@ __global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
 			a.out.v[(size_t)inst * a.Ptot + i] = 0.0;
 	__syncthreads();
 
+	HOQP_STAMP(0);
 	for (int k = 0; k < a.L; ++k) {
 		int m = a.m_inst ? a.m_inst[(size_t)inst * a.L + k] : a.m[k];
 		int p = a.p_inst ? a.p_inst[(size_t)inst * a.L + k] : a.p[k];
@@ -1043,6 +1115,7 @@ __global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
 	}
 	if (lane == 0 && a.out.status)
 		a.out.status[inst] = st.status;
+	HOQP_STAMP(7);
 #endif  // __HIP_DEVICE_COMPILE__
 }
 

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhoqp_hip.so")
+LIB_PATH = os.environ.get("HOQP_LIB", os.path.join(_HERE, "libhoqp_hip.so"))  # override: profiling build
 
 MAX_LEVELS = 8
 MAX_VARS = 32
