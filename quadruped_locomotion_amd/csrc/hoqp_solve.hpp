@@ -18,7 +18,7 @@ constexpr int NR = 32;	  // register-array length, >= HOQP_MAX_VARS
 constexpr int LDV = 34;	  // leading dimension of the reflector store (even: 16-byte aligned rows)
 constexpr int SROW = 32;  // row stride of the task staging buffer
 constexpr int XROWS = 16; // dumped unpivoted columns (over-determined least squares); aliases S
-constexpr int CHUNK = 8;  // task rows staged per pass
+constexpr int CHUNK = 16; // task rows staged per pass
 
 static_assert(NR >= HOQP_MAX_VARS, "register arrays must cover n");
 
@@ -73,7 +73,7 @@ __host__ __device__ inline LdsOff lds_offsets(const SolveArgs &a)
 	o.pivlane = take(4 * NR);
 	o.W = take(4 * NR);
 	o.xlane = take(4 * XROWS);
-	o.total = off;
+	o.total = off + 256;  // readable tail: full-width (NR) row reads may run past the last array
 	return o;
 }
 
@@ -108,6 +108,13 @@ __device__ inline Lds lds_bind(const SolveArgs &a, HOQP_LDS char *base)
 	l.xlane = (ldsi *)(base + o.xlane);
 	return l;
 }
+
+// Loads are issued unconditionally and masked afterwards: a load behind a condition becomes a
+// branch + load + wait per element (measured: the guarded form serialised every LDS read).
+// Callers keep the ADDRESS valid (clamped index); LDS has a readable tail pad for rows that
+// are read to their full NR extent.
+__device__ __forceinline__ double sel(bool on, double v) { return on ? v : 0.0; }
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // ---------------------------------------------------------------------------
 // Static-index row loops.  Register arrays may only be indexed by compile-time constants, but
@@ -240,7 +247,7 @@ __device__ inline void hh_apply_right_rows_reg(ldsd *A0, int n0, ldsd *A1, int n
 		double row[NR];
 #pragma unroll
 		for (int i = 0; i < NR; ++i)
-			row[i] = (i < nr) ? rowp[i] : 0.0;
+			row[i] = sel(i < nr, rowp[i]);
 		for (int k = ka; k < kb; ++k) {
 			const ldsd2 *vr2 = (const ldsd2 *)(VR + k * LDV);
 			double vv[NR];
@@ -272,7 +279,7 @@ __device__ inline double hh_apply_vec(double vi, int nr, int ka, int kb, bool fo
 	const int lane = lane_id();
 	for (int t = 0; t < kb - ka; ++t) {
 		int k = forward ? ka + t : kb - 1 - t;
-		double v = (lane >= k && lane < nr) ? l.TV[k * LDV + lane] : 0.0;
+		double v = sel(lane >= k && lane < nr, l.TV[k * LDV + (lane & (NR - 1))]);
 		double s = wave_sum(v * vi) * l.tau[k];
 		vi = fma(-s, v, vi);
 	}
@@ -304,15 +311,16 @@ __device__ inline double ls_solve_reg(int k1, int k2, double rhs_c, bool isB, in
 	l.rhs[lane] = rhs_c;
 	__syncthreads();
 	const bool act = lane < rb;
-	const double rp = act ? l.rhs[l.pivlane[k1 + lane]] : 0.0;  // rhs by pivot position
-	const double inv = act ? 1.0 / l.rdiag[k1 + lane] : 0.0;
+	const int pl = l.pivlane[k1 + (act ? lane : 0)];
+	const double rp = sel(act, l.rhs[pl]);  // rhs by pivot position
+	const double inv = sel(act, 1.0 / l.rdiag[k1 + (act ? lane : 0)]);
 	// row `lane` of L = R_B' (pivoted part): L(j, i) = R(i, j) = VR[(k1+j)*LDV + k1+i], i < j
 	double Lrow[NR];
 	{
 		const ldsd *vr = VR + (k1 + (act ? lane : 0)) * LDV + k1;
 #pragma unroll
 		for (int i = 0; i < NR; ++i)
-			Lrow[i] = (act && i < lane) ? vr[i] : 0.0;
+			Lrow[i] = sel(act && i < lane, vr[i]);
 	}
 	auto fwd = [&](double t) -> double {  // L y = t
 		double acc = t, y = 0.0;
@@ -333,7 +341,7 @@ __device__ inline double ls_solve_reg(int k1, int k2, double rhs_c, bool isB, in
 			double Urow[NR];
 #pragma unroll
 			for (int j = 0; j < NR; ++j)
-				Urow[j] = (act && j > lane && j < rb) ? VR[(k1 + j) * LDV + k1 + lane] : 0.0;
+				Urow[j] = sel(act && j > lane && j < rb, VR[(k1 + (j < rb ? j : 0)) * LDV + k1 + (act ? lane : 0)]);
 			double acc = q, z = 0.0;  // U z = q
 #pragma unroll
 			for (int i = NR - 1; i >= 0; --i) {
@@ -503,28 +511,41 @@ __device__ inline void project_task(const double *__restrict__ rows_g, const dou
 				    const Lds &l)
 {
 	const int lane = lane_id();
+	// staging map: half a wavefront per task row (lane & 31 = column, lane >> 5 = row parity);
+	// the next chunk's global loads are in flight while the current chunk is multiplied
+	const int c = lane & 31, h = lane >> 5;
+	const int cc = (c < nstore) ? c : 0;
+	double pre[CHUNK / 2];
+	double rv_next;
+	auto fetch = [&](int r0) {
+		const int nr = min(CHUNK, rows - r0);
+#pragma unroll
+		for (int t = 0; t < CHUNK / 2; ++t) {
+			const int r = 2 * t + h;
+			// clamped, never masked: rows >= nr are not read back, columns >= nstore meet zc == 0
+			pre[t] = rows_g[(size_t)(r0 + (r < nr ? r : 0)) * nstore + cc];
+		}
+		rv_next = rhs_g[r0 + (lane < nr ? lane : 0)];
+	};
+	fetch(0);
 	for (int r0 = 0; r0 < rows; r0 += CHUNK) {
 		const int nr = min(CHUNK, rows - r0);
+		__syncthreads();  // readers of the previous chunk are done with S
+#pragma unroll
+		for (int t = 0; t < CHUNK / 2; ++t)
+			l.S[(2 * t + h) * SROW + c] = pre[t];
+		const double rv = rv_next;
 		__syncthreads();
-		// coalesced stage of nr rows (nstore doubles each) into S[r*SROW + col]
-		for (int idx = lane; idx < nr * nstore; idx += kWave) {
-			int r = idx / nstore, c = idx - r * nstore;
-			if (c < n)
-				l.S[r * SROW + c] = rows_g[(size_t)r0 * nstore + idx];
-		}
-		double rv = (lane < nr) ? rhs_g[r0 + lane] : 0.0;
-		__syncthreads();
+		if (r0 + CHUNK < rows)
+			fetch(r0 + CHUNK);
 		for (int r = 0; r < nr; ++r) {
 			const ldsd2 *sr2 = (const ldsd2 *)(l.S + r * SROW);
 			double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-			for (int i = 0; i < NR; i += 2) {
-				if (i >= n)
-					continue;
-				d2v t = sr2[i >> 1];
+			rows_upto2(n, [&](int i) {
+				const d2v t = sr2[i >> 1];
 				a0 = fma(t.x, zc[i], a0);
-				a1 = (i + 1 < n) ? fma(t.y, zc[i + 1], a1) : a1;
-			}
+				a1 = fma(t.y, zc[i + 1], a1);
+			});
 			const double acc = a0 + a1;
 			const double rr = readlane_d(rv, r);
 			if (to_T) {
@@ -613,12 +634,12 @@ __device__ inline double eqp_step(const SolveArgs &a, const Lds &l, int nz, int 
 		}
 #pragma unroll
 		for (int i = 0; i < NR; ++i)
-			col[i] = (i < lim) ? src[i] : 0.0;
+			col[i] = sel(i < lim, src[i]);
 	}
 	__syncthreads();
 	int mypos = has ? -1 : -2;
-	const int k1 = hh_factor_reg(col, mypos, isC, nz, 0, 1e-12, l);
-	const int k2 = hh_factor_reg(col, mypos, has && !isC, nz, k1, 1e-11, l);
+	const int k1 = uni(hh_factor_reg(col, mypos, isC, nz, 0, 1e-12, l));
+	const int k2 = uni(hh_factor_reg(col, mypos, has && !isC, nz, k1, 1e-11, l));
 	*k1_out = k1;
 	// unpivoted B columns -> X
 	const bool unp = has && !isC && mypos == -1;
@@ -652,9 +673,11 @@ __device__ inline double eqp_step(const SolveArgs &a, const Lds &l, int nz, int 
 __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState &st, int inst, int k, int m, int p)
 {
 	const int lane = lane_id();
-	const int n = st.n, ld = a.ld;
-	const int nz = st.nz, P = st.P;
+	const int n = uni(st.n), ld = a.ld;
+	const int nz = uni(st.nz), P = uni(st.P);
 	const int nstore = a.n;
+	m = uni(m);
+	p = uni(p);
 	const int Pn = P + p;
 	const bool consider = (nz > 0) && (a.gate_prior ? (p > 0) : (p > 0 || P > 0));
 	// stored rows are still needed by a later level?  (else they are neither rotated nor kept)
@@ -672,7 +695,7 @@ __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState 
 		const bool live = (lane < nz) || (lane == 63);
 #pragma unroll
 		for (int i = 0; i < NR; ++i)
-			zc[i] = (live && i < n) ? src[i * stride] : 0.0;
+			zc[i] = sel(live && i < n, src[(i < n ? i : 0) * stride]);
 		if (m > 0)
 			project_task(a.A[k] + (size_t)inst * a.m[k] * nstore, a.b[k] + (size_t)inst * a.m[k], m, nstore, n,
 				     nz, ld, zc, true, 0, l);
@@ -693,12 +716,12 @@ __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState 
 			const ldsd *src = l.TV + (has ? lane : 0) * ld;
 #pragma unroll
 			for (int i = 0; i < NR; ++i)
-				col[i] = (has && i < nz) ? src[i] : 0.0;
+				col[i] = sel(has && i < nz, src[i]);
 		}
 		const double rhs_c = has ? l.rhs[lane] : 0.0;
 		__syncthreads();  // every column is in registers before TV is reused as the reflector store
 		int mypos = has ? -1 : -2;
-		rank = hh_factor_reg(col, mypos, has, nz, 0, kEpsMach * (double)max(m, nz), l);
+		rank = uni(hh_factor_reg(col, mypos, has, nz, 0, kEpsMach * (double)max(m, nz), l));
 		HOQP_STAMP(2);
 		const bool unp = has && mypos == -1;
 		const unsigned long long um = __ballot(unp);
@@ -826,7 +849,7 @@ __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState 
 					done = true;
 					break;
 				}
-				wmask &= ~(1ull << l.W[drop]);
+				wmask &= ~(1ull << uni(l.W[drop]));
 				__syncthreads();
 				if (lane == 0)
 					for (int j = drop; j < w - 1; ++j)
@@ -848,8 +871,8 @@ __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState 
 				const ldsd *bp = l.BL + (lane < m ? lane : 0) * ld;
 #pragma unroll
 				for (int i = 0; i < NR; ++i) {
-					grow[i] = (lane < Pn && i < nz) ? gp[i] : 0.0;
-					brow[i] = (lane < m && i < rank) ? bp[i] : 0.0;
+					grow[i] = sel(lane < Pn && i < nz, gp[i]);
+					brow[i] = sel(lane < m && i < rank, bp[i]);
 				}
 				const ldsd2 *p2 = (const ldsd2 *)l.tmp;
 #pragma unroll
@@ -955,7 +978,7 @@ __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState 
 		double row[NR];
 #pragma unroll
 		for (int i = 0; i < NR; ++i)
-			row[i] = (i < nz) ? rowp[i] : 0.0;
+			row[i] = sel(i < nz, rowp[i]);
 		double d0 = 0.0, d1 = 0.0;
 		const ldsd2 *y2 = (const ldsd2 *)l.tmp;
 #pragma unroll
@@ -1026,7 +1049,7 @@ __global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
 	if (inst >= a.batch)
 		return;
 	LevelState st;
-	st.n = a.n_inst ? a.n_inst[inst] : a.n;
+	st.n = uni(a.n_inst ? a.n_inst[inst] : a.n);
 	st.nz = st.n;
 	st.P = 0;
 	st.Pout = 0;
@@ -1047,8 +1070,8 @@ __global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
 
 	HOQP_STAMP(0);
 	for (int k = 0; k < a.L; ++k) {
-		int m = a.m_inst ? a.m_inst[(size_t)inst * a.L + k] : a.m[k];
-		int p = a.p_inst ? a.p_inst[(size_t)inst * a.L + k] : a.p[k];
+		int m = uni(a.m_inst ? a.m_inst[(size_t)inst * a.L + k] : a.m[k]);
+		int p = uni(a.p_inst ? a.p_inst[(size_t)inst * a.L + k] : a.p[k]);
 		solve_level(a, l, st, inst, k, m, p);
 	}
 
@@ -1063,22 +1086,25 @@ __global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
 		double xr[NR];
 #pragma unroll
 		for (int i = 0; i < NR; ++i)
-			xr[i] = (i < n) ? l.x[i] : 0.0;
+			xr[i] = sel(i < n, l.x[i]);
 		unsigned long long amask = 0ull;
 		int prow = 0;
 		for (int k = 0; k < a.L; ++k) {
-			int m = a.m_inst ? a.m_inst[(size_t)inst * a.L + k] : a.m[k];
-			int p = a.p_inst ? a.p_inst[(size_t)inst * a.L + k] : a.p[k];
+			const int m = uni(a.m_inst ? a.m_inst[(size_t)inst * a.L + k] : a.m[k]);
+			const int p = uni(a.p_inst ? a.p_inst[(size_t)inst * a.L + k] : a.p[k]);
 			double er = 0.0, iv = -1e300;
 			if (m > 0) {
 				double e = 0.0;
 				if (lane < m) {
 					const double *ar = a.A[k] + ((size_t)inst * a.m[k] + lane) * a.n;
 					double acc = -a.b[k][(size_t)inst * a.m[k] + lane];
+					double t[NR];
 #pragma unroll
 					for (int i = 0; i < NR; ++i)
-						if (i < n)
-							acc = fma(ar[i], xr[i], acc);
+						t[i] = ar[i < n ? i : 0];  // all loads in flight at once
+#pragma unroll
+					for (int i = 0; i < NR; ++i)
+						acc = fma(t[i], xr[i], acc);  // xr[i >= n] == 0
 					e = fabs(acc);
 				}
 				er = wave_max(e);
@@ -1088,10 +1114,13 @@ __global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
 				if (lane < p) {
 					const double *dr = a.D[k] + ((size_t)inst * a.p[k] + lane) * a.n;
 					double acc = -a.f[k][(size_t)inst * a.p[k] + lane];
+					double t[NR];
 #pragma unroll
 					for (int i = 0; i < NR; ++i)
-						if (i < n)
-							acc = fma(dr[i], xr[i], acc);
+						t[i] = dr[i < n ? i : 0];
+#pragma unroll
+					for (int i = 0; i < NR; ++i)
+						acc = fma(t[i], xr[i], acc);
 					e = acc;  // D x - f
 				}
 				iv = wave_max(e);
