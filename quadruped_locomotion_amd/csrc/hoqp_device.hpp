@@ -23,6 +23,16 @@ constexpr double kEpsMach = 2.220446049250313e-16;
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x; }
 
+// Ordering point between LDS writes and reads of different lanes.  The workgroup is a single
+// wavefront and the LDS pipeline executes one wavefront's instructions in issue order, so
+// only the COMPILER must be kept from reordering; __syncthreads() would add a full
+// s_waitcnt lgkmcnt(0) drain (one LDS round trip, ~100+ cycles) at every call.
+__device__ __forceinline__ void wave_sync()
+{
+	__builtin_amdgcn_wave_barrier();
+	asm volatile("" ::: "memory");
+}
+
 // ---------------------------------------------------------------------------
 // cross-lane primitives (DPP butterflies inside 16-lane rows, readlane across rows)
 // ---------------------------------------------------------------------------

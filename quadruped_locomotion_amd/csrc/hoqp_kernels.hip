@@ -429,8 +429,8 @@ static int launch_solve(hoqp_handle *h, SolveArgs &a, hipStream_t s)
 	// profiling build: per-section cycle stamps of one launch, printed to stderr
 	unsigned long long *dbg = nullptr;
 	if (getenv("HOQP_DBG") && a.batch > 0) {
-		HIP_OK(h, hipMalloc(&dbg, sizeof(unsigned long long) * 8 * a.batch));
-		HIP_OK(h, hipMemset(dbg, 0, sizeof(unsigned long long) * 8 * a.batch));
+		HIP_OK(h, hipMalloc(&dbg, sizeof(unsigned long long) * 16 * a.batch));
+		HIP_OK(h, hipMemset(dbg, 0, sizeof(unsigned long long) * 16 * a.batch));
 	}
 	a.dbg = dbg;
 	struct Dump {
@@ -443,18 +443,19 @@ static int launch_solve(hoqp_handle *h, SolveArgs &a, hipStream_t s)
 			if (!d)
 				return;
 			(void)hipStreamSynchronize(s);
-			std::vector<unsigned long long> host((size_t)8 * batch);
+			std::vector<unsigned long long> host((size_t)16 * batch);
 			(void)hipMemcpy(host.data(), d, host.size() * 8, hipMemcpyDeviceToHost);
-			double sum[8] = {0};
+			double sum[16] = {0};
 			for (int i = 0; i < batch; ++i)
-				for (int j = 0; j < 8; ++j)
-					sum[j] += (double)host[(size_t)i * 8 + j];
-			static const char *nm[8] = {"init", "project", "factor", "ls/bl", "rotate", "qp", "update", "tail"};
+				for (int j = 0; j < 16; ++j)
+					sum[j] += (double)host[(size_t)i * 16 + j];
+			static const char *nm[16] = {"init", "project", "factor", "ls/bl", "rotate", "qp.misc", "update", "tail",
+						     "eqp.load+W", "eqp.B", "eqp.ls", "eqp.Qp", "qp.mult", "qp.search", "-", "-"};
 			double tot = 0;
-			for (int j = 0; j < 8; ++j)
+			for (int j = 0; j < 16; ++j)
 				tot += sum[j];
-			fprintf(stderr, "[hoqp profile] memtime ticks (100 MHz) per instance:");
-			for (int j = 0; j < 8; ++j)
+			fprintf(stderr, "[hoqp profile] shader cycles per instance:");
+			for (int j = 0; j < 14; ++j)
 				fprintf(stderr, " %s=%.0f", nm[j], sum[j] / batch);
 			fprintf(stderr, " total=%.0f\n", tot / batch);
 			(void)hipFree(d);

@@ -1,9 +1,11 @@
 // hoqp_solve.hpp -- the per-instance HO-QP solve (device code, gfx950).
 //
 // One workgroup == one wavefront == one instance.  Master copies of the small matrices live
-// in LDS; every O(n^2)/O(n^3) loop runs on REGISTER-resident rows/columns (one row or column
-// per lane, compile-time unrolled over NR = 32 entries), so the inner loops are pure fp64
-// FMAs with broadcast LDS reads of the shared operand (Householder vector, staged task row).
+// in LDS.  The O(n^2)/O(n^3) loops run on register tiles with a 2-D lane map: a lane is
+// (s, c) = (lane & 3, lane >> 2); a "panel" holds up to 64 vectors of length <= 32, vector
+// q = c + 16*slot owned by the four lanes of quad c, lane s holding entries s, s+4, s+8, ...
+// (NT = 8 per vector).  Dot products are 8 FMAs + a two-step DPP quad reduction, and the
+// entry range [k, nr) of Householder step k shrinks uniformly over the four lanes.
 //
 // Algorithm: DESIGN.md section 3.  Reference: src/control/ho_qp/ho_qp_problem.cpp:11-357.
 #pragma once
@@ -14,13 +16,17 @@
 
 namespace hoqp {
 
-constexpr int NR = 32;	  // register-array length, >= HOQP_MAX_VARS
-constexpr int LDV = 34;	  // leading dimension of the reflector store (even: 16-byte aligned rows)
+constexpr int NR = 32;	  // vector length capacity, >= HOQP_MAX_VARS
+constexpr int NT = NR / 4; // entries of one vector held by one lane
+constexpr int NSP = 4;	  // panel slots: 64 columns  (working set + LS rows + violated rows)
+constexpr int NSR = 6;	  // row slots: 96 rows >= HOQP_MAX_VARS + HOQP_MAX_INEQ_ROWS
+constexpr int LDV = 34;	  // leading dimension of the reflector store
 constexpr int SROW = 32;  // row stride of the task staging buffer
-constexpr int XROWS = 16; // dumped unpivoted columns (over-determined least squares); aliases S
+constexpr int XROWS = 16; // dumped unpivoted columns (rank-deficient least squares); aliases S
 constexpr int CHUNK = 16; // task rows staged per pass
 
-static_assert(NR >= HOQP_MAX_VARS, "register arrays must cover n");
+static_assert(NR >= HOQP_MAX_VARS, "register tiles must cover n");
+static_assert(16 * NSR >= HOQP_MAX_VARS + HOQP_MAX_INEQ_ROWS, "row slots must cover Z and G");
 
 struct SolveArgs {
 	int batch, n, L;
@@ -35,12 +41,12 @@ struct SolveArgs {
 	int ld;	   // odd leading dimension >= n of Z, G, BL, X
 	int use_bl;	   // some level needs its equality rows inside the active-set loop
 	int last_ineq_use; // last level that looks at stored inequality rows (rows are dropped after it)
-	unsigned long long *dbg;  // HOQP_PROFILE builds only: [batch][8] cycle stamps per section
+	unsigned long long *dbg;  // HOQP_PROFILE builds only: [batch][16] cycle stamps per section
 };
 
 // byte offsets of the LDS arrays (shared by host sizing and device addressing)
 struct LdsOff {
-	int Z, x, G, g, s, c, TV, S, BL, r0, rho, tau, rdiag, rhs, X, tmp, pivlane, W, xlane, total;
+	int Z, x, G, g, s, c, TV, S, BL, r0, rho, a0, tau, rdiag, rhs, X, tmp, pivlane, W, xlane, colpos, vlist, total;
 };
 
 __host__ __device__ inline LdsOff lds_offsets(const SolveArgs &a)
@@ -65,6 +71,7 @@ __host__ __device__ inline LdsOff lds_offsets(const SolveArgs &a)
 	o.BL = take(8 * ((mm && a.use_bl) ? mm : 1) * ld);
 	o.r0 = take(8 * (mm + 1));
 	o.rho = take(8 * (mm + 1));
+	o.a0 = take(8 * (mm + 1));
 	o.tau = take(8 * NR);
 	o.rdiag = take(8 * NR);
 	o.rhs = take(8 * kWave);
@@ -73,14 +80,16 @@ __host__ __device__ inline LdsOff lds_offsets(const SolveArgs &a)
 	o.pivlane = take(4 * NR);
 	o.W = take(4 * NR);
 	o.xlane = take(4 * XROWS);
-	o.total = off + 256;  // readable tail: full-width (NR) row reads may run past the last array
+	o.colpos = take(4 * kWave);
+	o.vlist = take(4 * kWave);
+	o.total = off + 256;  // readable tail: full-width (NR) vector reads may run past the last array
 	return o;
 }
 
 #ifdef __HIP_DEVICE_COMPILE__
 struct Lds {
-	ldsd *Z, *x, *G, *g, *s, *c, *TV, *S, *BL, *r0, *rho, *tau, *rdiag, *rhs, *X, *tmp;
-	ldsi *pivlane, *W, *xlane;
+	ldsd *Z, *x, *G, *g, *s, *c, *TV, *S, *BL, *r0, *rho, *a0, *tau, *rdiag, *rhs, *X, *tmp;
+	ldsi *pivlane, *W, *xlane, *colpos, *vlist;
 };
 
 __device__ inline Lds lds_bind(const SolveArgs &a, HOQP_LDS char *base)
@@ -98,6 +107,7 @@ __device__ inline Lds lds_bind(const SolveArgs &a, HOQP_LDS char *base)
 	l.BL = (ldsd *)(base + o.BL);
 	l.r0 = (ldsd *)(base + o.r0);
 	l.rho = (ldsd *)(base + o.rho);
+	l.a0 = (ldsd *)(base + o.a0);
 	l.tau = (ldsd *)(base + o.tau);
 	l.rdiag = (ldsd *)(base + o.rdiag);
 	l.rhs = (ldsd *)(base + o.rhs);
@@ -106,171 +116,262 @@ __device__ inline Lds lds_bind(const SolveArgs &a, HOQP_LDS char *base)
 	l.pivlane = (ldsi *)(base + o.pivlane);
 	l.W = (ldsi *)(base + o.W);
 	l.xlane = (ldsi *)(base + o.xlane);
+	l.colpos = (ldsi *)(base + o.colpos);
+	l.vlist = (ldsi *)(base + o.vlist);
 	return l;
 }
 
 // Loads are issued unconditionally and masked afterwards: a load behind a condition becomes a
 // branch + load + wait per element (measured: the guarded form serialised every LDS read).
-// Callers keep the ADDRESS valid (clamped index); LDS has a readable tail pad for rows that
-// are read to their full NR extent.
+// Callers keep the ADDRESS valid (clamped index); LDS has a readable tail pad for vectors
+// that are read to their full NR extent.
 __device__ __forceinline__ double sel(bool on, double v) { return on ? v : 0.0; }
+
+// Pins a loaded value in a register.  Without it the compiler turns `cond ? load : 0` back
+// into a branch around the load (select-with-load -> branch in CodeGenPrepare), which
+// serialises the loads: exec-mask juggling plus one s_waitcnt per element.  Always load a
+// whole group first, then pin the group (the waits then come in issue order).
+__device__ __forceinline__ void pin(double &v) { asm volatile("" : "+v"(v)); }
+
+// u[t] = p[4 t], t < NT: one lane's entries of a vector stored with unit stride
+// (p already includes the lane's entry offset s)
+__device__ __forceinline__ void load8(double (&u)[NT], const ldsd *p)
+{
+#pragma unroll
+	for (int t = 0; t < NT; ++t)
+		u[t] = p[4 * t];
+#pragma unroll
+	for (int t = 0; t < NT; ++t)
+		pin(u[t]);
+}
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// ---------------------------------------------------------------------------
-// Static-index row loops.  Register arrays may only be indexed by compile-time constants, but
-// the active row range [k, nr) is run-time (wave-uniform).  rows_from2 walks the rows in
-// blocks of 8 (pairs inside a block): blocks entirely outside [k, nr) are skipped by a scalar
-// branch, blocks entirely inside run unmasked, only the block containing k carries
-// per-element masks.  body(i, on0, on1) handles rows i, i+1; onX == false means "row < k".
-// ---------------------------------------------------------------------------
-template <typename Body>
-__device__ __forceinline__ void rows_from2(int k, int nr, Body body)
+// sum over the four lanes of a quad (quad_perm [1,0,3,2] then [2,3,0,1]); all four get it
+__device__ __forceinline__ double quad_sum(double v)
 {
-#pragma unroll
-	for (int b = 0; b < NR / 8; ++b) {
-		if (8 * b + 8 <= k || 8 * b >= nr)
-			continue;
-		if (8 * b >= k) {
-#pragma unroll
-			for (int j = 0; j < 8; j += 2)
-				body(8 * b + j, true, true);
-		} else {
-#pragma unroll
-			for (int j = 0; j < 8; j += 2)
-				body(8 * b + j, 8 * b + j >= k, 8 * b + j + 1 >= k);
-		}
-	}
-}
-
-// rows [0, nr) in pairs, whole blocks of 8 skipped beyond nr (entries in [nr, 8*ceil) must be benign)
-template <typename Body>
-__device__ __forceinline__ void rows_upto2(int nr, Body body)
-{
-#pragma unroll
-	for (int b = 0; b < NR / 8; ++b) {
-		if (8 * b >= nr)
-			continue;
-#pragma unroll
-		for (int j = 0; j < 8; j += 2)
-			body(8 * b + j);
-	}
+	v += dpp_d<0xB1>(v);
+	v += dpp_d<0x4E>(v);
+	return v;
 }
 
 // ---------------------------------------------------------------------------
-// Householder QR with column pivoting, ONE COLUMN PER LANE IN REGISTERS.
-//   col[0..nr)  : this lane's column (entries >= nr must be 0)
-//   mypos       : -1 = active (unpivoted) column, >= 0 = pivoted at that step, -2 = no column
-//   cand        : this lane's column may be chosen as a pivot in this call
-// Step k: the pivot lane dumps its column into VR[k*LDV + i]; rows >= k of that row are the
-// Householder vector (v_k at i == k), rows < k the R entries R(i, k); rdiag[k] = R(k, k),
-// tau[k] = 2 / v'v, pivlane[k] = pivot lane.  Stops when the largest remaining candidate
-// column norm is <= rtol * (first pivot norm of this call).  Returns the new step count.
+// Static-index entry loops.  Lane s holds entries i = s + 4t (t = 0..NT-1) of a vector in
+// registers x[t]; register arrays may only be indexed by compile-time constants, the active
+// entry range [k, nr) is run-time.  The loops are STRAIGHT-LINE over all NT entries with a
+// per-lane mask `on`: a version that skipped inactive blocks with wave-uniform branches was
+// measured 3x slower (a taken scalar branch costs far more than the 8 masked FMAs it saves).
+// Entries >= nr of every register vector are kept at zero.
 // ---------------------------------------------------------------------------
-__device__ inline int hh_factor_reg(double (&col)[NR], int &mypos, bool cand, int nr, int k0, double rtol,
-				    const Lds &l)
+template <typename Body>
+__device__ __forceinline__ void t_from(int k, int nr, int s, Body body)
 {
-	const int lane = lane_id();
+	(void)nr;
+#pragma unroll
+	for (int t = 0; t < NT; ++t)
+		body(t, s + 4 * t >= k, true);
+}
+
+// entries [0, nr): `on` == false for entries >= nr
+template <typename Body>
+__device__ __forceinline__ void t_upto(int nr, int s, Body body)
+{
+#pragma unroll
+	for (int t = 0; t < NT; ++t)
+		body(t, s + 4 * t < nr);
+}
+
+// ---------------------------------------------------------------------------
+// Householder QR with column pivoting on a register panel.
+//   x[sl][t]   : entry s+4t of column q = c + 16*sl (entries >= nr must be 0)
+//   pos[sl]    : -1 = active (unpivoted) column, >= 0 = pivoted at that step, -2 = no column
+//   [qlo, qhi) : columns that may be chosen as pivots in this call
+// Step k: the pivot quad dumps its column into VR[k*LDV + i]; entries >= k of that row are the
+// Householder vector (v_k at i == k), entries < k the R entries R(i, k); rdiag[k] = R(k, k),
+// tau[k] = 2 / v'v, pivlane[k] = pivot column, colpos[column] = k.  Stops when the largest
+// remaining candidate column norm is <= rtol * (first pivot norm of this call).  Returns the
+// new step count.
+// ---------------------------------------------------------------------------
+__device__ inline int panel_factor(double (&x)[NSP][NT], int (&pos)[NSP], int nslot, int qlo, int qhi, int nr, int k0,
+				   double rtol, const Lds &l)
+{
+	const int lane = lane_id(), s = lane & 3, c = lane >> 2;
 	ldsd *VR = l.TV;
 	int k = k0;
 	double first = -1.0;
 	while (k < nr) {
-		double s0 = 0.0, s1 = 0.0;
-		rows_from2(k, nr, [&](int i, bool on0, bool on1) {
-			const double a = on0 ? col[i] : 0.0;
-			const double b = on1 ? col[i + 1] : 0.0;
-			s0 = fma(a, a, s0);
-			s1 = fma(b, b, s1);
-		});
-		const bool mine = (mypos == -1) && cand;
-		int pc;
-		double best = wave_argmax(mine ? (s0 + s1) : -1.0, mine ? lane : -1, &pc);
-		if (pc < 0 || !(best > 0.0))
+		double best = -1.0;
+		int bq = -1;
+#pragma unroll
+		for (int sl = 0; sl < NSP; ++sl) {
+			if (sl >= nslot)
+				continue;
+			double a0 = 0.0, a1 = 0.0;
+			t_from(k, nr, s, [&](int t, bool on, bool) {
+				const double v = on ? x[sl][t] : 0.0;
+				if (t & 1)
+					a1 = fma(v, v, a1);
+				else
+					a0 = fma(v, v, a0);
+			});
+			const double ss = quad_sum(a0 + a1);
+			const int q = c + 16 * sl;
+			const bool mine = pos[sl] == -1 && q >= qlo && q < qhi;
+			const bool take = mine && ss > best;
+			best = take ? ss : best;
+			bq = take ? q : bq;
+		}
+		int pq;
+		const double bmax = wave_argmax(best, bq, &pq);
+		if (pq < 0 || !(bmax > 0.0))
 			break;
-		const double nrm = sqrt(best);
+		const double nrm = sqrt(bmax);
 		if (first < 0.0)
 			first = nrm;
 		if (!(nrm > rtol * first))
 			break;
+		const int pc = pq & 15, ps = pq >> 4;
 		ldsd *vr = VR + k * LDV;
-		if (lane == pc) {
-			ldsd2 *w2 = (ldsd2 *)vr;
-			rows_upto2(nr, [&](int i) {
-				d2v t;
-				t.x = col[i];
-				t.y = col[i + 1];
-				w2[i >> 1] = t;
-			});
-			mypos = k;
+		if (c == pc) {
+#pragma unroll
+			for (int sl = 0; sl < NSP; ++sl) {
+				if (sl != ps)
+					continue;
+				t_upto(nr, s, [&](int t, bool) { vr[s + 4 * t] = x[sl][t]; });
+				pos[sl] = k;
+			}
 		}
-		__syncthreads();
-		const double alpha = vr[k];
+		wave_sync();
+		double alpha = vr[k];
+		double vv[NT];
+		load8(vv, vr + s);
+		pin(alpha);
 		const double beta = (alpha >= 0.0) ? -nrm : nrm;
 		const double v0 = alpha - beta;
 		const double tk = 1.0 / (nrm * (nrm + fabs(alpha)));
-		if (mypos == -1) {
-			double vv[NR];
-			const ldsd2 *vr2 = (const ldsd2 *)vr;
+		t_from(k, nr, s, [&](int t, bool on, bool) {
+			const double u = (s + 4 * t == k) ? v0 : vv[t];
+			vv[t] = on ? u : 0.0;
+		});
+#pragma unroll
+		for (int sl = 0; sl < NSP; ++sl) {
+			if (sl >= nslot)
+				continue;
 			double d0 = 0.0, d1 = 0.0;
-			rows_from2(k, nr, [&](int i, bool on0, bool on1) {
-				const d2v t = vr2[i >> 1];
-				vv[i] = on0 ? ((i == k) ? v0 : t.x) : 0.0;
-				vv[i + 1] = on1 ? ((i + 1 == k) ? v0 : t.y) : 0.0;
-				d0 = fma(vv[i], col[i], d0);
-				d1 = fma(vv[i + 1], col[i + 1], d1);
+			t_from(k, nr, s, [&](int t, bool, bool) {
+				if (t & 1)
+					d1 = fma(vv[t], x[sl][t], d1);
+				else
+					d0 = fma(vv[t], x[sl][t], d0);
 			});
-			const double d = (d0 + d1) * tk;
-			rows_from2(k, nr, [&](int i, bool, bool) {
-				col[i] = fma(-d, vv[i], col[i]);
-				col[i + 1] = fma(-d, vv[i + 1], col[i + 1]);
-			});
+			double d = quad_sum(d0 + d1) * tk;
+			d = (pos[sl] == -1) ? d : 0.0;
+			t_from(k, nr, s, [&](int t, bool, bool) { x[sl][t] = fma(-d, vv[t], x[sl][t]); });
 		}
 		if (lane == 0) {
 			vr[k] = v0;  // program order: after every lane's read of vr[k] above
 			l.tau[k] = tk;
 			l.rdiag[k] = beta;
-			l.pivlane[k] = pc;
+			l.pivlane[k] = pq;
+			l.colpos[pq] = k;
 		}
 		++k;
 	}
-	__syncthreads();
+	wave_sync();
 	return k;
 }
 
 // rows <- rows * H_ka ... H_(kb-1): reflectors [ka, kb) applied from the right to row-major
-// rows (one row per lane, in registers).  Rows r < n0 come from A0, the rest from A1.
-__device__ inline void hh_apply_right_rows_reg(ldsd *A0, int n0, ldsd *A1, int n1, int ldr, int nr, int ka,
-					       int kb, const Lds &l)
+// rows.  Row r = c + 16*slot is a vector owned by quad c; rows r < n0 come from A0, the rest
+// from A1.
+__device__ inline void rows_apply_reflectors(ldsd *A0, int n0, ldsd *A1, int n1, int ldr, int nr, int ka, int kb,
+					     const Lds &l)
 {
+	const int lane = lane_id(), s = lane & 3, c = lane >> 2;
+	const int R = n0 + n1;
 	const ldsd *VR = l.TV;
-	for (int r = lane_id(); r < n0 + n1; r += kWave) {
-		ldsd *rowp = (r < n0) ? A0 + r * ldr : A1 + (r - n0) * ldr;
-		double row[NR];
-#pragma unroll
-		for (int i = 0; i < NR; ++i)
-			row[i] = sel(i < nr, rowp[i]);
-		for (int k = ka; k < kb; ++k) {
-			const ldsd2 *vr2 = (const ldsd2 *)(VR + k * LDV);
-			double vv[NR];
-			double d0 = 0.0, d1 = 0.0;
-			rows_from2(k, nr, [&](int i, bool on0, bool on1) {
-				const d2v t = vr2[i >> 1];
-				vv[i] = on0 ? t.x : 0.0;
-				vv[i + 1] = on1 ? t.y : 0.0;
-				d0 = fma(vv[i], row[i], d0);
-				d1 = fma(vv[i + 1], row[i + 1], d1);
-			});
-			const double d = (d0 + d1) * l.tau[k];
-			rows_from2(k, nr, [&](int i, bool, bool) {
-				row[i] = fma(-d, vv[i], row[i]);
-				row[i + 1] = fma(-d, vv[i + 1], row[i + 1]);
-			});
-		}
-#pragma unroll
-		for (int i = 0; i < NR; ++i)
-			if (i < nr)
-				rowp[i] = row[i];
+	if (R <= 0 || kb <= ka) {
+		wave_sync();
+		return;
 	}
-	__syncthreads();
+	double x[NSR][NT];
+	ldsd *rowp[NSR];
+	bool valid[NSR];
+#pragma unroll
+	for (int sl = 0; sl < NSR; ++sl) {
+		if (16 * sl >= R)
+			continue;
+		const int r = c + 16 * sl;
+		valid[sl] = r < R;
+		const int rr = valid[sl] ? r : 0;
+		rowp[sl] = (rr < n0) ? A0 + rr * ldr : A1 + (rr - n0) * ldr;
+		load8(x[sl], rowp[sl] + s);
+		t_upto(nr, s, [&](int t, bool on) { x[sl][t] = sel(on && valid[sl], x[sl][t]); });
+	}
+	for (int k = ka; k < kb; ++k) {
+		const ldsd *vr = VR + k * LDV;
+		double tk = l.tau[k];
+		double vv[NT];
+		load8(vv, vr + s);
+		pin(tk);
+		t_from(k, nr, s, [&](int t, bool on, bool) { vv[t] = sel(on, vv[t]); });
+#pragma unroll
+		for (int sl = 0; sl < NSR; ++sl) {
+			if (16 * sl >= R)
+				continue;
+			double d0 = 0.0, d1 = 0.0;
+			t_from(k, nr, s, [&](int t, bool, bool) {
+				if (t & 1)
+					d1 = fma(vv[t], x[sl][t], d1);
+				else
+					d0 = fma(vv[t], x[sl][t], d0);
+			});
+			const double d = quad_sum(d0 + d1) * tk;
+			t_from(k, nr, s, [&](int t, bool, bool) { x[sl][t] = fma(-d, vv[t], x[sl][t]); });
+		}
+	}
+#pragma unroll
+	for (int sl = 0; sl < NSR; ++sl) {
+		if (16 * sl >= R)
+			continue;
+		t_upto(nr, s, [&](int t, bool on) {
+			if (on && valid[sl])
+				rowp[sl][s + 4 * t] = x[sl][t];
+		});
+	}
+	wave_sync();
+}
+
+// out[r] = rows[r][0..nr) . vec[0..nr) for r < R (row r owned by quad r & 15, slot r >> 4)
+template <int NS>
+__device__ inline void rows_dot(const ldsd *A, int R, int ldr, int nr, const ldsd *vec, ldsd *out)
+{
+	const int lane = lane_id(), s = lane & 3, c = lane >> 2;
+	if (R <= 0)
+		return;
+	double vv[NT];
+	load8(vv, vec + s);
+	t_upto(nr, s, [&](int t, bool on) { vv[t] = sel(on, vv[t]); });
+#pragma unroll
+	for (int sl = 0; sl < NS; ++sl) {
+		if (16 * sl >= R)
+			continue;
+		const int r = c + 16 * sl;
+		const bool valid = r < R;
+		const ldsd *rowp = A + (valid ? r : 0) * ldr;
+		double d0 = 0.0, d1 = 0.0;
+		double ev[NT];
+		load8(ev, rowp + s);
+		t_upto(nr, s, [&](int t, bool on) {
+			const double e = sel(on, ev[t]);
+			if (t & 1)
+				d1 = fma(e, vv[t], d1);
+			else
+				d0 = fma(e, vv[t], d0);
+		});
+		const double d = quad_sum(d0 + d1);
+		if (valid && s == 0)
+			out[r] = d;
+	}
 }
 
 // One entry per lane.  forward: vec <- H_(kb-1) ... H_ka vec ; else vec <- H_ka ... H_(kb-1) vec.
@@ -288,28 +389,29 @@ __device__ inline double hh_apply_vec(double vi, int nr, int ka, int kb, bool fo
 
 // ---------------------------------------------------------------------------
 // Least squares on a finished factorization.  Pivot positions [k1, k2) hold the factor R_B
-// (rb = k2 - k1 rows) of the "B" columns; `rhs_c` is this lane's right-hand side (lane ==
-// column); `isB` marks lanes that own a B column, mypos their pivot position (or -1).
+// (rb = k2 - k1 rows) of the "B" columns [qB0, qB1); the right-hand side is in l.rhs[column],
+// the pivot position of a column in l.colpos[column] (-1 = unpivoted).
 // Solves min |R_B' q - rhs| and returns q_j in lane j (j < rb); *res_norm2 = |residual|^2.
 // eps != 0 adds the first order effect of the reference's eps*I term
 // (ho_qp_problem.cpp:244-246):  q <- q - eps (R_B R_B')^-1 q.
 // Unpivoted B columns (over-determined case) must have been dumped by the caller to
 // l.X[u*ld + i] with their lanes listed in l.xlane[0..nunp).
 // ---------------------------------------------------------------------------
-__device__ inline double ls_solve_reg(int k1, int k2, double rhs_c, bool isB, int mypos, int nunp, double eps,
-				      int ld, double *res_norm2, const Lds &l)
+__device__ inline double ls_solve_reg(int k1, int k2, int qB0, int qB1, int nunp, double eps, int ld,
+				      double *res_norm2, const Lds &l)
 {
 	const int lane = lane_id();
 	const int rb = k2 - k1;
 	const ldsd *VR = l.TV;
+	wave_sync();
+	const bool isB = lane >= qB0 && lane < qB1;  // lane == column here
+	const double rhs_c = l.rhs[lane];
+	const int mypos = l.colpos[lane];
 	if (rb <= 0) {
 		if (res_norm2)
 			*res_norm2 = wave_sum(isB ? rhs_c * rhs_c : 0.0);
 		return 0.0;
 	}
-	__syncthreads();
-	l.rhs[lane] = rhs_c;
-	__syncthreads();
 	const bool act = lane < rb;
 	const int pl = l.pivlane[k1 + (act ? lane : 0)];
 	const double rp = sel(act, l.rhs[pl]);  // rhs by pivot position
@@ -320,7 +422,13 @@ __device__ inline double ls_solve_reg(int k1, int k2, double rhs_c, bool isB, in
 		const ldsd *vr = VR + (k1 + (act ? lane : 0)) * LDV + k1;
 #pragma unroll
 		for (int i = 0; i < NR; ++i)
-			Lrow[i] = sel(act && i < lane, vr[i]);
+			Lrow[i] = vr[i];
+#pragma unroll
+		for (int i = 0; i < NR; ++i)
+			pin(Lrow[i]);
+#pragma unroll
+		for (int i = 0; i < NR; ++i)
+			Lrow[i] = sel(act && i < lane, Lrow[i]);
 	}
 	auto fwd = [&](double t) -> double {  // L y = t
 		double acc = t, y = 0.0;
@@ -341,7 +449,13 @@ __device__ inline double ls_solve_reg(int k1, int k2, double rhs_c, bool isB, in
 			double Urow[NR];
 #pragma unroll
 			for (int j = 0; j < NR; ++j)
-				Urow[j] = sel(act && j > lane && j < rb, VR[(k1 + (j < rb ? j : 0)) * LDV + k1 + (act ? lane : 0)]);
+				Urow[j] = VR[(k1 + (j < rb ? j : 0)) * LDV + k1 + (act ? lane : 0)];
+#pragma unroll
+			for (int j = 0; j < NR; ++j)
+				pin(Urow[j]);
+#pragma unroll
+			for (int j = 0; j < NR; ++j)
+				Urow[j] = sel(act && j > lane && j < rb, Urow[j]);
 			double acc = q, z = 0.0;  // U z = q
 #pragma unroll
 			for (int i = NR - 1; i >= 0; --i) {
@@ -431,14 +545,14 @@ __device__ inline double ls_solve_reg(int k1, int k2, double rhs_c, bool isB, in
 				continue;
 			const double zi = readlane_d(acc * cinv, i);
 			z = (lane == i) ? zi : z;
-			__syncthreads();
+			wave_sync();
 			if (lane == i) {
 #pragma unroll
 				for (int j = 0; j < NR; ++j)
 					if (j < i)
 						l.tmp[32 + j] = Crow[j];
 			}
-			__syncthreads();
+			wave_sync();
 			if (lane < i)
 				acc = fma(-l.tmp[32 + lane], zi, acc);
 		}
@@ -476,41 +590,61 @@ __device__ inline double ls_solve_reg(int k1, int k2, double rhs_c, bool isB, in
 		return acc;
 	};
 	double q = chol_solve(RB_vec());  // l.rhs holds rhs per column
-	__syncthreads();
+	wave_sync();
 	if (act)
 		l.tmp[lane] = q;
-	__syncthreads();
+	wave_sync();
 	double res = residual(rhs_c);
-	__syncthreads();
+	wave_sync();
 	l.rhs[lane] = res;
-	__syncthreads();
+	wave_sync();
 	q += chol_solve(RB_vec());  // one refinement step
 	if (eps != 0.0)
 		q -= eps * chol_solve(q);
-	__syncthreads();
+	wave_sync();
 	if (act)
 		l.tmp[lane] = q;
-	__syncthreads();
+	wave_sync();
 	if (res_norm2) {
 		res = residual(rhs_c);
 		*res_norm2 = wave_sum(res * res);
 	}
-	__syncthreads();
+	wave_sync();
 	return act ? q : 0.0;
 }
 
 
+
 // ---------------------------------------------------------------------------
-// Task projection.  Lane j < nz owns column j of Z (zc[l] = Z[l][j]); lane 63 owns x.
-// For every staged task row a_r:  lane j gets (a_r Z)_j, lane 63 gets a_r x.
-//   to_T : (A Z)' -> TV[r*ld + j] (column r of the QR workspace), rhs -> l.rhs[r] = b_r - a_r x
-//   else : D Z   -> G[(P+r)*ld + j],                              g[P+r]       = f_r - d_r x
+// Task projection.  Two task rows per pass: lanes 0-31 take row 2i, lanes 32-63 row 2i+1
+// (one row per pass in the rare case nz == 32).  Within a half, lane j < nz owns column j
+// of Z (zc[i] = Z[i][j]) and the spare lane (31 of the half) owns x.  For a staged task
+// row a_r:  lane j gets (a_r Z)_j, the spare lane gets a_r x.
+//   to_T : (A Z)' -> TV[r*ld + j] (vector r of the QR panel), rhs -> l.rhs[r] = b_r - a_r x
+//   else : D Z   -> G[(P+r)*ld + j],                           g[P+r]       = f_r - d_r x
 // ---------------------------------------------------------------------------
+struct ProjLane {
+	bool dual, isZ, isX;
+	int j;
+};
+
+__device__ __forceinline__ ProjLane proj_lane(int nz)
+{
+	const int lane = lane_id();
+	ProjLane p;
+	p.dual = nz < 32;
+	p.j = p.dual ? (lane & 31) : lane;
+	p.isZ = p.j < nz;
+	p.isX = p.dual ? ((lane & 31) == 31) : (lane == 63);
+	return p;
+}
+
 __device__ inline void project_task(const double *__restrict__ rows_g, const double *__restrict__ rhs_g, int rows,
 				    int nstore, int n, int nz, int ld, const double (&zc)[NR], bool to_T, int P,
 				    const Lds &l)
 {
 	const int lane = lane_id();
+	const ProjLane pl = proj_lane(nz);
 	// staging map: half a wavefront per task row (lane & 31 = column, lane >> 5 = row parity);
 	// the next chunk's global loads are in flight while the current chunk is multiplied
 	const int c = lane & 31, h = lane >> 5;
@@ -522,7 +656,7 @@ __device__ inline void project_task(const double *__restrict__ rows_g, const dou
 #pragma unroll
 		for (int t = 0; t < CHUNK / 2; ++t) {
 			const int r = 2 * t + h;
-			// clamped, never masked: rows >= nr are not read back, columns >= nstore meet zc == 0
+			// clamped, never masked: rows >= nr are not used, columns >= nstore meet zc == 0
 			pre[t] = rows_g[(size_t)(r0 + (r < nr ? r : 0)) * nstore + cc];
 		}
 		rv_next = rhs_g[r0 + (lane < nr ? lane : 0)];
@@ -530,38 +664,46 @@ __device__ inline void project_task(const double *__restrict__ rows_g, const dou
 	fetch(0);
 	for (int r0 = 0; r0 < rows; r0 += CHUNK) {
 		const int nr = min(CHUNK, rows - r0);
-		__syncthreads();  // readers of the previous chunk are done with S
+		wave_sync();  // readers of the previous chunk are done with S
 #pragma unroll
 		for (int t = 0; t < CHUNK / 2; ++t)
 			l.S[(2 * t + h) * SROW + c] = pre[t];
 		const double rv = rv_next;
-		__syncthreads();
+		wave_sync();
 		if (r0 + CHUNK < rows)
 			fetch(r0 + CHUNK);
-		for (int r = 0; r < nr; ++r) {
+		const int npass = pl.dual ? (nr + 1) >> 1 : nr;
+		for (int i = 0; i < npass; ++i) {
+			const int r = pl.dual ? 2 * i + h : i;  // this lane's row (r == nr: odd tail, discarded)
 			const ldsd2 *sr2 = (const ldsd2 *)(l.S + r * SROW);
 			double a0 = 0.0, a1 = 0.0;
-			rows_upto2(n, [&](int i) {
-				const d2v t = sr2[i >> 1];
-				a0 = fma(t.x, zc[i], a0);
-				a1 = fma(t.y, zc[i + 1], a1);
-			});
+			// all 16 reads are issued back to back (one LDS round trip per row pair); entries
+			// >= n multiply zc == 0
+#pragma unroll
+			for (int e = 0; e < NR; e += 2) {
+				const d2v t = sr2[e >> 1];
+				a0 = fma(t.x, zc[e], a0);
+				a1 = fma(t.y, zc[e + 1], a1);
+			}
 			const double acc = a0 + a1;
-			const double rr = readlane_d(rv, r);
+			const int ra = pl.dual ? 2 * i : i;
+			const double rrA = readlane_d(rv, ra), rrB = readlane_d(rv, (ra + 1) & 63);
+			const double rr = (pl.dual && h) ? rrB : rrA;
+			const bool rok = r < nr;
 			if (to_T) {
-				if (lane < nz)
-					l.TV[(r0 + r) * ld + lane] = acc;
-				if (lane == 63)
+				if (pl.isZ && rok)
+					l.TV[(r0 + r) * ld + pl.j] = acc;
+				if (pl.isX && rok)
 					l.rhs[r0 + r] = rr - acc;
 			} else {
-				if (lane < nz)
-					l.G[(P + r0 + r) * ld + lane] = acc;
-				if (lane == 63)
+				if (pl.isZ && rok)
+					l.G[(P + r0 + r) * ld + pl.j] = acc;
+				if (pl.isX && rok)
 					l.g[P + r0 + r] = rr - acc;
 			}
 		}
 	}
-	__syncthreads();
+	wave_sync();
 }
 
 #ifdef HOQP_PROFILE
@@ -569,7 +711,7 @@ __device__ inline void project_task(const double *__restrict__ rows_g, const dou
 	do {                                                                          \
 		unsigned long long now_ = __builtin_amdgcn_s_memtime();               \
 		if (a.dbg && lane_id() == 0)                                          \
-			a.dbg[(size_t)blockIdx.x * 8 + (slot)] += now_ - st.t_last;   \
+			a.dbg[(size_t)blockIdx.x * 16 + (slot)] += now_ - st.t_last;  \
 		st.t_last = __builtin_amdgcn_s_memtime();                             \
 	} while (0)
 #else
@@ -586,18 +728,27 @@ struct LevelState {
 	unsigned long long t_last;
 };
 
-// ---------------------------------------------------------------------------
-// Equality-constrained least-squares step of the active-set method, factored from scratch:
-//   min |B (y+p) - ...|  s.t.  G_W p = 0, minimum norm.  Lane c owns column c of
-//   [ G_W' | B0' | G_V' ]  (w + m + |V| <= 64 columns).
-// Returns p_i in lane i; *k1_out = rank of the working set (reflectors [0,k1) stay in TV).
-// ---------------------------------------------------------------------------
-__device__ inline double eqp_step(const SolveArgs &a, const Lds &l, int nz, int rank, int m, int w,
-				  unsigned long long vmask, int *k1_out, bool *overflow)
+// number the quads' unpivoted columns of one slot: u = base + (rank of this quad among them)
+__device__ __forceinline__ int unp_index(bool unp, int &base)
 {
 	const int lane = lane_id();
+	const unsigned long long bm = __ballot(unp && (lane & 3) == 0);
+	const int u = base + __popcll(bm & ((1ull << (lane & ~3)) - 1ull));
+	base += __popcll(bm);
+	return u;
+}
+
+// ---------------------------------------------------------------------------
+// Equality-constrained least-squares step of the active-set method, factored from scratch:
+//   min |B (y+p) - ...|  s.t.  G_W p = 0, minimum norm.  The panel holds the columns of
+//   [ G_W' | B0' | G_V' ]  (w + m + |V| <= 64 columns, rows of V listed in l.vlist).
+// Returns p_i in lane i; *k1_out = rank of the working set (reflectors [0,k1) stay in TV).
+// ---------------------------------------------------------------------------
+__device__ inline double eqp_step(const SolveArgs &a, const Lds &l, LevelState &st, int nz, int rank, int m, int w,
+				  int nV, int *k1_out, bool *overflow)
+{
+	const int lane = lane_id(), s = lane & 3, c = lane >> 2;
 	const int ld = a.ld;
-	const int nV = __popcll(vmask);
 	const int nb = m + nV;
 	const int ncol = w + nb;
 	*k1_out = 0;
@@ -605,66 +756,79 @@ __device__ inline double eqp_step(const SolveArgs &a, const Lds &l, int nz, int 
 		*overflow = true;
 		return 0.0;
 	}
-	double col[NR];
-	double rhs_c = 0.0;
-	const bool has = lane < ncol;
-	const bool isC = lane < w;
-	{
-		const ldsd *src = l.G;
-		int lim = nz;
-		if (has) {
-			if (isC) {
-				src = l.G + l.W[lane] * ld;
-			} else if (lane < w + m) {
-				int j = lane - w;
-				src = l.BL + j * ld;
-				lim = rank;
-				rhs_c = -l.rho[j];
-			} else {
-				int t = lane - w - m;
-				unsigned long long mk = vmask;
-				for (int q = 0; q < t; ++q)
-					mk &= mk - 1;
-				int r = __ffsll((long long)mk) - 1;
-				src = l.G + r * ld;
-				rhs_c = -l.s[r];
-			}
-		} else {
-			lim = 0;
-		}
+	const int nslot = (ncol + 15) >> 4;
+	double x[NSP][NT];
+	int pos[NSP];
+	wave_sync();
 #pragma unroll
-		for (int i = 0; i < NR; ++i)
-			col[i] = sel(i < lim, src[i]);
+	for (int sl = 0; sl < NSP; ++sl) {
+		pos[sl] = -2;
+		if (sl >= nslot)
+			continue;
+		const int q = c + 16 * sl;
+		const bool has = q < ncol;
+		const bool isW = q < w, isL = q >= w && q < w + m;
+		const int wq = l.W[isW ? q : 0];
+		const int vq = l.vlist[(has && !isW && !isL) ? q - w - m : 0];
+		const int grow = has ? (isW ? wq : (isL ? 0 : vq)) : 0;
+		const ldsd *src = isL ? l.BL + (q - w) * ld : l.G + grow * ld;
+		const int lim = isL ? rank : nz;
+		load8(x[sl], src + s);
+		t_upto(nz, s, [&](int t, bool) { x[sl][t] = sel(has && s + 4 * t < lim, x[sl][t]); });
+		pos[sl] = has ? -1 : -2;
 	}
-	__syncthreads();
-	int mypos = has ? -1 : -2;
-	const int k1 = uni(hh_factor_reg(col, mypos, isC, nz, 0, 1e-12, l));
-	const int k2 = uni(hh_factor_reg(col, mypos, has && !isC, nz, k1, 1e-11, l));
+	{
+		// right-hand side and pivot map per column (lane == column)
+		double rc = 0.0;
+		if (lane >= w && lane < w + m)
+			rc = -l.rho[lane - w];
+		else if (lane >= w + m && lane < ncol)
+			rc = -l.s[l.vlist[lane - w - m]];
+		l.rhs[lane] = rc;
+		l.colpos[lane] = -1;
+	}
+	wave_sync();
+	const int k1 = uni(panel_factor(x, pos, nslot, 0, w, nz, 0, 1e-12, l));
+	HOQP_STAMP(8);
+	const int k2 = uni(panel_factor(x, pos, nslot, w, ncol, nz, k1, 1e-11, l));
+	HOQP_STAMP(9);
 	*k1_out = k1;
 	// unpivoted B columns -> X
-	const bool unp = has && !isC && mypos == -1;
-	const unsigned long long um = __ballot(unp);
-	const int nunp = __popcll(um);
-	if (nunp > XROWS) {
-		*overflow = true;
-		return 0.0;
-	}
-	if (unp) {
-		int u = __popcll(um & ((1ull << lane) - 1ull));
-		ldsd *xr = l.X + u * ld;
+	int nunp = 0;
+	if (k2 - k1 < nb) {
 #pragma unroll
-		for (int i = 0; i < NR; ++i)
-			if (i < nz)
-				xr[i] = col[i];
-		l.xlane[u] = lane;
+		for (int sl = 0; sl < NSP; ++sl) {
+			if (sl >= nslot)
+				continue;
+			const int q = c + 16 * sl;
+			const bool unp = pos[sl] == -1 && q >= w;
+			const int u = unp_index(unp, nunp);
+			if (unp && u < XROWS) {
+				ldsd *xr = l.X + u * ld;
+				t_upto(nz, s, [&](int t, bool on) {
+					if (on)
+						xr[s + 4 * t] = x[sl][t];
+				});
+				if (s == 0)
+					l.xlane[u] = q;
+			}
+		}
+		nunp = uni(nunp);
+		if (nunp > XROWS) {
+			*overflow = true;
+			return 0.0;
+		}
 	}
-	__syncthreads();
-	double q = ls_solve_reg(k1, k2, rhs_c, has && !isC, mypos, nunp, 0.0, ld, nullptr, l);
+	wave_sync();
+	double q = ls_solve_reg(k1, k2, w, ncol, nunp, 0.0, ld, nullptr, l);
+	HOQP_STAMP(10);
 	// u = [0 (k1) ; q ; 0],  p = Q u
 	int srcl = lane - k1;
 	double qq = __shfl(q, srcl < 0 ? 0 : srcl);
 	double u = (srcl >= 0 && srcl < k2 - k1) ? qq : 0.0;
-	return hh_apply_vec(u, nz, 0, k2, false, l);
+	const double pi = hh_apply_vec(u, nz, 0, k2, false, l);
+	HOQP_STAMP(11);
+	return pi;
 }
 
 // ---------------------------------------------------------------------------
@@ -672,7 +836,7 @@ __device__ inline double eqp_step(const SolveArgs &a, const Lds &l, int nz, int 
 // ---------------------------------------------------------------------------
 __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState &st, int inst, int k, int m, int p)
 {
-	const int lane = lane_id();
+	const int lane = lane_id(), s = lane & 3, c = lane >> 2;
 	const int n = uni(st.n), ld = a.ld;
 	const int nz = uni(st.nz), P = uni(st.P);
 	const int nstore = a.n;
@@ -690,12 +854,19 @@ __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState 
 	//         ho_qp_problem.cpp:180-285, in factored form) ----
 	{
 		double zc[NR];
-		const ldsd *src = (lane < nz) ? l.Z + lane : l.x;
-		const int stride = (lane < nz) ? ld : 1;
-		const bool live = (lane < nz) || (lane == 63);
+		const ProjLane pl = proj_lane(nz);
+		const ldsd *src = pl.isZ ? l.Z + pl.j : l.x;
+		const int stride = pl.isZ ? ld : 1;
+		const bool live = pl.isZ || pl.isX;
 #pragma unroll
 		for (int i = 0; i < NR; ++i)
-			zc[i] = sel(live && i < n, src[(i < n ? i : 0) * stride]);
+			zc[i] = src[(i < n ? i : 0) * stride];
+#pragma unroll
+		for (int i = 0; i < NR; ++i)
+			pin(zc[i]);
+#pragma unroll
+		for (int i = 0; i < NR; ++i)
+			zc[i] = sel(live && i < n, zc[i]);
 		if (m > 0)
 			project_task(a.A[k] + (size_t)inst * a.m[k] * nstore, a.b[k] + (size_t)inst * a.m[k], m, nstore, n,
 				     nz, ld, zc, true, 0, l);
@@ -710,71 +881,95 @@ __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState 
 	int rank = 0;
 	double yi = 0.0;  // lane i holds y_i (rotated coordinates)
 	if (m > 0 && nz > 0) {
-		double col[NR];
-		const bool has = lane < m;
-		{
-			const ldsd *src = l.TV + (has ? lane : 0) * ld;
+		double x[NSP][NT];
+		int pos[NSP];
+		const int nslot = (m + 15) >> 4;
 #pragma unroll
-			for (int i = 0; i < NR; ++i)
-				col[i] = sel(has && i < nz, src[i]);
+		for (int sl = 0; sl < NSP; ++sl) {
+			pos[sl] = -2;
+			if (sl >= nslot)
+				continue;
+			const int q = c + 16 * sl;
+			const bool has = q < m;
+			const ldsd *src = l.TV + (has ? q : 0) * ld;
+			load8(x[sl], src + s);
+			t_upto(nz, s, [&](int t, bool on) { x[sl][t] = sel(on && has, x[sl][t]); });
+			pos[sl] = has ? -1 : -2;
 		}
-		const double rhs_c = has ? l.rhs[lane] : 0.0;
-		__syncthreads();  // every column is in registers before TV is reused as the reflector store
-		int mypos = has ? -1 : -2;
-		rank = uni(hh_factor_reg(col, mypos, has, nz, 0, kEpsMach * (double)max(m, nz), l));
+		l.colpos[lane] = -1;
+		wave_sync();  // every column is in registers before TV is reused as the reflector store
+		rank = uni(panel_factor(x, pos, nslot, 0, m, nz, 0, kEpsMach * (double)max(m, nz), l));
 		HOQP_STAMP(2);
-		const bool unp = has && mypos == -1;
-		const unsigned long long um = __ballot(unp);
-		const int nunp = __popcll(um);
-		const int myu = __popcll(um & ((1ull << lane) - 1ull));
+		int nunp = 0;
+		int uidx[NSP];
+#pragma unroll
+		for (int sl = 0; sl < NSP; ++sl) {
+			uidx[sl] = 0;
+			if (sl >= nslot || rank == m)
+				continue;
+			uidx[sl] = unp_index(pos[sl] == -1, nunp);
+		}
+		nunp = uni(nunp);
 		if (consider) {
 			// LS rows in rotated coordinates for the active-set loop: BL[j][0..rank), r0[j];
 			// row order: pivot positions first, then the unpivoted (dependent) rows
-			if (has) {
-				int j = unp ? rank + myu : mypos;
+#pragma unroll
+			for (int sl = 0; sl < NSP; ++sl) {
+				if (sl >= nslot)
+					continue;
+				const int q = c + 16 * sl;
+				const bool hasc = pos[sl] != -2;
+				const bool unp = pos[sl] == -1;
+				const int mp = pos[sl];
+				const int j = hasc ? (unp ? rank + uidx[sl] : mp) : 0;
 				ldsd *row = l.BL + j * ld;
-				if (unp) {
-#pragma unroll
-					for (int i = 0; i < NR; ++i)
-						if (i < rank)
-							row[i] = col[i];
-				} else {
-					const ldsd *vr = l.TV + mypos * LDV;
-#pragma unroll
-					for (int i = 0; i < NR; ++i)
-						if (i < rank)
-							row[i] = (i < mypos) ? vr[i] : (i == mypos ? l.rdiag[mypos] : 0.0);
-				}
-				l.r0[j] = rhs_c;
+				const double dg = l.rdiag[mp > 0 ? mp : 0];
+				const double rq = l.rhs[q];
+				t_upto(rank, s, [&](int t, bool on) {
+					const int i = s + 4 * t;
+					const double v = unp ? x[sl][t] : (i < mp ? x[sl][t] : (i == mp ? dg : 0.0));
+					if (on && hasc)
+						row[i] = v;
+				});
+				if (s == 0 && hasc)
+					l.r0[j] = rq;
 			}
 		} else if (rank > 0) {
 			// ---- 4a. unconstrained level: y1 = argmin |R' y1 - r| (+ eps term), y2 = 0 ----
 			if (nunp > XROWS) {
 				st.status |= HOQP_STATUS_WORKSPACE;
 			} else {
-				if (unp) {
-					ldsd *xr = l.X + myu * ld;
+				if (nunp > 0) {
 #pragma unroll
-					for (int i = 0; i < NR; ++i)
-						if (i < nz)
-							xr[i] = col[i];
-					l.xlane[myu] = lane;
+					for (int sl = 0; sl < NSP; ++sl) {
+						if (sl >= nslot)
+							continue;
+						const bool unp = pos[sl] == -1;
+						ldsd *xr = l.X + (unp ? uidx[sl] : 0) * ld;
+						t_upto(nz, s, [&](int t, bool on) {
+							if (on && unp)
+								xr[s + 4 * t] = x[sl][t];
+						});
+						if (s == 0 && unp)
+							l.xlane[uidx[sl]] = c + 16 * sl;
+					}
 				}
-				__syncthreads();
-				yi = ls_solve_reg(0, rank, rhs_c, has, mypos, nunp, a.eps, ld, &level_res2, l);
+				wave_sync();
+				yi = ls_solve_reg(0, rank, 0, m, nunp, a.eps, ld, &level_res2, l);
 			}
 		} else {
-			level_res2 = wave_sum(has ? rhs_c * rhs_c : 0.0);
+			const double r = sel(lane < m, l.rhs[lane]);
+			level_res2 = wave_sum(r * r);
 		}
-		__syncthreads();
+		wave_sync();
 		HOQP_STAMP(3);
 		// ---- 3. rotate Z and every stored inequality row: Z <- Z Q, G <- G Q ----
 		if (rank > 0)
-			hh_apply_right_rows_reg(l.Z, n, l.G, Pg, ld, nz, 0, rank, l);
+			rows_apply_reflectors(l.Z, n, l.G, Pg, ld, nz, 0, rank, l);
 		HOQP_STAMP(4);
 	} else if (m > 0) {
 		// no free directions left: the residual is what it is
-		double r = (lane < m) ? l.rhs[lane] : 0.0;
+		double r = sel(lane < m, l.rhs[lane]);
 		level_res2 = wave_sum(r * r);
 	}
 
@@ -784,7 +979,7 @@ __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState 
 			l.s[lane] = -l.g[lane];
 		if (lane < m)
 			l.rho[lane] = -l.r0[lane];
-		__syncthreads();
+		wave_sync();
 		const unsigned long long softmask = (p >= 64) ? ~0ull : (((1ull << p) - 1ull) << P);
 		const unsigned long long hardmask = (P >= 64) ? ~0ull : ((1ull << P) - 1ull);
 		unsigned long long wmask = 0ull;
@@ -796,17 +991,22 @@ __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState 
 			if (__ballot(bad))
 				st.status |= HOQP_STATUS_INFEASIBLE_START;
 		}
-		const double gl = (lane < Pn) ? l.g[lane] : 0.0;
+		const double gl = sel(lane < Pn, l.g[lane < Pn ? lane : 0]);
 		const bool isSoft = lane < Pn && ((softmask >> lane) & 1ull);
 		const double tolv = 1e-11 * (1.0 + fabs(gl));
 		bool done = false;
 		for (iters = 0; iters < a.max_iter && !done; ++iters) {
-			const double si = (lane < Pn) ? l.s[lane] : 0.0;
-			const double rj = (lane < m) ? l.rho[lane] : 0.0;
-			const unsigned long long vmask = __ballot(isSoft && si > tolv);
+			const double si = sel(lane < Pn, l.s[lane < Pn ? lane : 0]);
+			const double rj = sel(lane < m, l.rho[lane < m ? lane : 0]);
+			const bool viol = isSoft && si > tolv;
+			const unsigned long long vmask = __ballot(viol);
+			const int nV = __popcll(vmask);
+			if (viol)
+				l.vlist[__popcll(vmask & ((1ull << lane) - 1ull))] = lane;
 			int k1 = 0;
 			bool overflow = false;
-			const double pi = eqp_step(a, l, nz, rank, m, w, vmask, &k1, &overflow);
+			HOQP_STAMP(5);
+			const double pi = eqp_step(a, l, st, nz, rank, m, w, nV, &k1, &overflow);
 			if (overflow) {
 				st.status |= HOQP_STATUS_WORKSPACE;
 				break;
@@ -842,54 +1042,32 @@ __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState 
 					if (lane < i)
 						acc = fma(-l.TV[i * LDV + lane], mi, acc);
 				}
-				int wi = (lane < k1) ? l.pivlane[lane] : -1;  // pivot lane == position in W
+				int wi = (lane < k1) ? l.pivlane[lane] : -1;  // pivot column == position in W
 				int drop;
 				double worst = wave_argmin((lane < k1) ? mu : 1e300, wi, &drop);
+				HOQP_STAMP(12);
 				if (!(worst < -1e-9 * (1.0 + gn)) || drop < 0) {
 					done = true;
 					break;
 				}
 				wmask &= ~(1ull << uni(l.W[drop]));
-				__syncthreads();
+				wave_sync();
 				if (lane == 0)
 					for (int j = drop; j < w - 1; ++j)
 						l.W[j] = l.W[j + 1];
 				--w;
-				__syncthreads();
+				wave_sync();
 				continue;
 			}
 			// c_i = G_i p for every row, a0_j = B0_j p   (p broadcast through LDS)
-			__syncthreads();
+			wave_sync();
 			l.tmp[lane] = (lane < nz) ? pi : 0.0;
-			__syncthreads();
-			double c0 = 0.0, c1 = 0.0, b0 = 0.0, b1 = 0.0;
-			{
-				// this lane's inequality row and LS row (reloaded per iteration: keeping them
-				// live across eqp_step would spill)
-				double grow[NR], brow[NR];
-				const ldsd *gp = l.G + (lane < Pn ? lane : 0) * ld;
-				const ldsd *bp = l.BL + (lane < m ? lane : 0) * ld;
-#pragma unroll
-				for (int i = 0; i < NR; ++i) {
-					grow[i] = sel(lane < Pn && i < nz, gp[i]);
-					brow[i] = sel(lane < m && i < rank, bp[i]);
-				}
-				const ldsd2 *p2 = (const ldsd2 *)l.tmp;
-#pragma unroll
-				for (int i = 0; i < NR; i += 2) {
-					if (i >= nz)
-						continue;
-					d2v t = p2[i >> 1];
-					c0 = fma(grow[i], t.x, c0);
-					c1 = fma(grow[i + 1], t.y, c1);
-					b0 = fma(brow[i], t.x, b0);
-					b1 = fma(brow[i + 1], t.y, b1);
-				}
-			}
-			const double ci = c0 + c1, a0 = b0 + b1;
-			if (lane < Pn)
-				l.c[lane] = ci;
-			__syncthreads();
+			wave_sync();
+			rows_dot<4>(l.G, Pn, ld, nz, l.tmp, l.c);
+			rows_dot<2>(l.BL, m, ld, rank, l.tmp, l.a0);
+			wave_sync();
+			const double ci = sel(lane < Pn, l.c[lane < Pn ? lane : 0]);
+			const double a0 = sel(lane < m, l.a0[lane < m ? lane : 0]);
 			const double q0 = wave_sum(a0 * rj), q1 = wave_sum(a0 * a0);
 			// ratio test on hard rows outside the working set
 			const bool isHard = lane < P && ((hardmask >> lane) & 1ull) && !((wmask >> lane) & 1ull);
@@ -940,7 +1118,7 @@ __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState 
 				t_star = (t_hi < 1e299) ? t_hi : t_lo;
 			const double t = fmin(t_star, t_hard);
 			yi = fma(t, pi, yi);
-			__syncthreads();
+			wave_sync();
 			if (lane < Pn)
 				l.s[lane] = fma(t, ci, si);
 			if (lane < m)
@@ -956,12 +1134,13 @@ __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState 
 					break;
 				}
 			}
-			__syncthreads();
+			wave_sync();
+			HOQP_STAMP(13);
 		}
 		if (!done)
 			st.status |= HOQP_STATUS_MAX_ITER;
 		{
-			double rj = (lane < m) ? l.rho[lane] : 0.0;
+			double rj = sel(lane < m, l.rho[lane < m ? lane : 0]);
 			level_res2 = wave_sum(rj * rj);
 		}
 	}
@@ -969,45 +1148,67 @@ __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState 
 	HOQP_STAMP(5);
 	// ---- 5./6. x_k = x_{k-1} + (Z Q) y (GetSolution, ho_qp_problem.cpp:46-51); slack bookkeeping
 	//            (ConstructFVector, :207-229); Z_k = Z_{k-1} Q2, G <- G Q2 (:172-178) ----
-	__syncthreads();
+	wave_sync();
 	l.tmp[lane] = (lane < nz) ? yi : 0.0;
-	__syncthreads();
-	for (int r = lane; r < n + Pg; r += kWave) {
-		const bool isZ = r < n;
-		ldsd *rowp = isZ ? l.Z + r * ld : l.G + (r - n) * ld;
-		double row[NR];
+	wave_sync();
+	{
+		const int R = n + Pg;
+		double yv[NT];
+		load8(yv, l.tmp + s);
+		t_upto(nz, s, [&](int t, bool on) { yv[t] = sel(on, yv[t]); });
+		double x[NSR][NT];
+		double dd[NSR];
+		// every load of every slot precedes the first shifted store (single wavefront, LDS in order)
 #pragma unroll
-		for (int i = 0; i < NR; ++i)
-			row[i] = sel(i < nz, rowp[i]);
-		double d0 = 0.0, d1 = 0.0;
-		const ldsd2 *y2 = (const ldsd2 *)l.tmp;
-#pragma unroll
-		for (int i = 0; i < NR; i += 2) {
-			if (i >= nz)
+		for (int sl = 0; sl < NSR; ++sl) {
+			if (16 * sl >= R)
 				continue;
-			d2v t = y2[i >> 1];
-			d0 = fma(row[i], t.x, d0);
-			d1 = fma(row[i + 1], t.y, d1);
+			const int r = c + 16 * sl;
+			const int rr = (r < R) ? r : 0;
+			const ldsd *rowp = (rr < n) ? l.Z + rr * ld : l.G + (rr - n) * ld;
+			double d0 = 0.0, d1 = 0.0;
+			load8(x[sl], rowp + s);
+			t_upto(nz, s, [&](int t, bool on) {
+				x[sl][t] = sel(on, x[sl][t]);
+				if (t & 1)
+					d1 = fma(x[sl][t], yv[t], d1);
+				else
+					d0 = fma(x[sl][t], yv[t], d0);
+			});
+			dd[sl] = quad_sum(d0 + d1);
 		}
-		const double d = d0 + d1;
-		if (isZ) {
-			l.x[r] += d;
-		} else {
-			const int gr = r - n;
-			double gi = l.g[gr] - d;
-			if (gr >= P) {
-				// v* = (D x - f)_+ ; the row becomes hard with rhs f + v* - D x
-				if (a.out.v)
-					a.out.v[(size_t)inst * a.Ptot + st.Pout + (gr - P)] = fmax(0.0, -gi);
-				gi = fmax(gi, 0.0);
-			}
-			l.g[gr] = gi;
-		}
-		if (rank > 0) {
+		wave_sync();
 #pragma unroll
-			for (int i = 0; i < NR; ++i)
-				if (i >= rank && i < nz)
-					rowp[i - rank] = row[i];
+		for (int sl = 0; sl < NSR; ++sl) {
+			if (16 * sl >= R)
+				continue;
+			const int r = c + 16 * sl;
+			const bool valid = r < R;
+			const int rr = valid ? r : 0;
+			const bool isZ = rr < n;
+			ldsd *rowp = isZ ? l.Z + rr * ld : l.G + (rr - n) * ld;
+			const double d = dd[sl];
+			if (valid && s == 0) {
+				if (isZ) {
+					l.x[rr] += d;
+				} else {
+					const int gr = rr - n;
+					double gi = l.g[gr] - d;
+					if (gr >= P) {
+						// v* = (D x - f)_+ ; the row becomes hard with rhs f + v* - D x
+						if (a.out.v)
+							a.out.v[(size_t)inst * a.Ptot + st.Pout + (gr - P)] = fmax(0.0, -gi);
+						gi = fmax(gi, 0.0);
+					}
+					l.g[gr] = gi;
+				}
+			}
+			if (rank > 0 && valid) {
+				t_from(rank, nz, s, [&](int t, bool on, bool) {
+					if (on && s + 4 * t < nz)
+						rowp[s + 4 * t - rank] = x[sl][t];
+				});
+			}
 		}
 	}
 	if (lane == 0) {
@@ -1023,7 +1224,7 @@ __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState 
 	st.nz = nz - rank;
 	st.P = keep_rows ? Pn : 0;
 	st.Pout += p;
-	__syncthreads();
+	wave_sync();
 	HOQP_STAMP(6);
 
 	if (a.out.x_levels && lane < a.n)
@@ -1031,8 +1232,8 @@ __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState 
 	if (a.out.Z_levels) {
 		double *Zo = a.out.Z_levels + ((size_t)inst * a.L + k) * a.n * a.n;
 		for (int idx = lane; idx < a.n * a.n; idx += kWave) {
-			int r = idx / a.n, c = idx - r * a.n;
-			Zo[idx] = (r < n && c < st.nz) ? l.Z[r * ld + c] : 0.0;
+			int r = idx / a.n, c2 = idx - r * a.n;
+			Zo[idx] = (r < n && c2 < st.nz) ? l.Z[r * ld + c2] : 0.0;
 		}
 	}
 }
@@ -1066,7 +1267,7 @@ __global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
 	if (a.out.v)
 		for (int i = lane; i < a.Ptot; i += kWave)
 			a.out.v[(size_t)inst * a.Ptot + i] = 0.0;
-	__syncthreads();
+	wave_sync();
 
 	HOQP_STAMP(0);
 	for (int k = 0; k < a.L; ++k) {
@@ -1086,7 +1287,13 @@ __global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
 		double xr[NR];
 #pragma unroll
 		for (int i = 0; i < NR; ++i)
-			xr[i] = sel(i < n, l.x[i]);
+			xr[i] = l.x[i];
+#pragma unroll
+		for (int i = 0; i < NR; ++i)
+			pin(xr[i]);
+#pragma unroll
+		for (int i = 0; i < NR; ++i)
+			xr[i] = sel(i < n, xr[i]);
 		unsigned long long amask = 0ull;
 		int prow = 0;
 		for (int k = 0; k < a.L; ++k) {

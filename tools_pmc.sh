@@ -1,0 +1,17 @@
+#!/bin/bash
+# PMC passes over the bench (one counter group per run, as the pool rules require)
+set -e
+export TMPDIR=/tmp
+OUT=$PWD/gpurun_out/pmc
+mkdir -p $OUT
+cd /tmp
+timeout -s KILL 120 rocprofv3 --list-avail > $OUT/avail.txt 2>&1 || true
+run() { # name counters...
+  name=$1; shift
+  timeout -s KILL 90 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 3 --warmup 1 > $OUT/$name.log 2>&1
+}
+cd $GRAFT_REPO_ROOT
+run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_IFETCH
+run sq2 SQ_INST_CYCLES_VMEM SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA
+run sqc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE
+echo done
