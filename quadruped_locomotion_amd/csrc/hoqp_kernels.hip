@@ -450,13 +450,13 @@ static int launch_solve(hoqp_handle *h, SolveArgs &a, hipStream_t s)
 				for (int j = 0; j < 16; ++j)
 					sum[j] += (double)host[(size_t)i * 16 + j];
 			static const char *nm[16] = {"init", "project", "factor", "ls/bl", "rotate", "qp.misc", "update", "tail",
-						     "eqp.load+W", "eqp.B", "eqp.ls", "eqp.Qp", "qp.mult", "qp.search", "-", "-"};
+						     "eqp.load+W", "eqp.B", "eqp.ls", "eqp.Qp", "qp.mult", "qp.search", "#eqp", "#eqp.csne"};
 			double tot = 0;
-			for (int j = 0; j < 16; ++j)
+			for (int j = 0; j < 14; ++j)
 				tot += sum[j];
 			fprintf(stderr, "[hoqp profile] shader cycles per instance:");
-			for (int j = 0; j < 14; ++j)
-				fprintf(stderr, " %s=%.0f", nm[j], sum[j] / batch);
+			for (int j = 0; j < 16; ++j)
+				fprintf(stderr, j < 14 ? " %s=%.0f" : " %s=%.3f", nm[j], sum[j] / batch);
 			fprintf(stderr, " total=%.0f\n", tot / batch);
 			(void)hipFree(d);
 		}

@@ -388,6 +388,83 @@ __device__ inline double hh_apply_vec(double vi, int nr, int ka, int kb, bool fo
 }
 
 // ---------------------------------------------------------------------------
+// Triangular solves on the reflector store, one row per lane.  Pivot positions [k1, k1+rb)
+// hold R (rb x rb, upper): R(i, j) = VR[(k1+j)*LDV + k1+i] for i < j, R(j, j) = rdiag[k1+j].
+//   Lrow: row `lane` of L = R'  (L(lane, i) = R(i, lane), i < lane; contiguous in VR)
+//   Urow: row `lane` of U = R   (U(lane, j) = R(lane, j), j > lane; strided in VR)
+// The substitution loops are static over NR in blocks of 8 (one scalar branch per block).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void load_Lrow(double (&Lrow)[NR], int k1, int rb, const Lds &l)
+{
+	const int lane = lane_id();
+	const bool act = lane < rb;
+	const ldsd *vr = l.TV + (k1 + (act ? lane : 0)) * LDV + k1;
+#pragma unroll
+	for (int i = 0; i < NR; ++i)
+		Lrow[i] = vr[i];
+#pragma unroll
+	for (int i = 0; i < NR; ++i)
+		pin(Lrow[i]);
+#pragma unroll
+	for (int i = 0; i < NR; ++i)
+		Lrow[i] = sel(act && i < lane, Lrow[i]);
+}
+
+__device__ __forceinline__ void load_Urow(double (&Urow)[NR], int k1, int rb, const Lds &l)
+{
+	const int lane = lane_id();
+	const bool act = lane < rb;
+	const ldsd *vc = l.TV + k1 * LDV + k1 + (act ? lane : 0);
+#pragma unroll
+	for (int j = 0; j < NR; ++j)
+		Urow[j] = vc[(j < rb ? j : 0) * LDV];
+#pragma unroll
+	for (int j = 0; j < NR; ++j)
+		pin(Urow[j]);
+#pragma unroll
+	for (int j = 0; j < NR; ++j)
+		Urow[j] = sel(act && j > lane && j < rb, Urow[j]);
+}
+
+// L y = t  (inv = 1 / L(lane, lane), 0 for lanes >= rb); returns y_lane
+__device__ __forceinline__ double tri_fwd(const double (&Lrow)[NR], double inv, double t, int rb)
+{
+	const int lane = lane_id();
+	double acc = t, y = 0.0;
+#pragma unroll
+	for (int b = 0; b < NR / 8; ++b) {
+		if (8 * b >= rb)
+			continue;
+#pragma unroll
+		for (int i = 8 * b; i < 8 * b + 8; ++i) {
+			const double yi = readlane_d(acc * inv, i);
+			y = (lane == i) ? yi : y;
+			acc = fma(-Lrow[i], yi, acc);
+		}
+	}
+	return y;
+}
+
+// U z = t; returns z_lane
+__device__ __forceinline__ double tri_bwd(const double (&Urow)[NR], double inv, double t, int rb)
+{
+	const int lane = lane_id();
+	double acc = t, z = 0.0;
+#pragma unroll
+	for (int b = NR / 8 - 1; b >= 0; --b) {
+		if (8 * b >= rb)
+			continue;
+#pragma unroll
+		for (int i = 8 * b + 7; i >= 8 * b; --i) {
+			const double zi = readlane_d(acc * inv, i);
+			z = (lane == i) ? zi : z;
+			acc = fma(-Urow[i], zi, acc);
+		}
+	}
+	return z;
+}
+
+// ---------------------------------------------------------------------------
 // Least squares on a finished factorization.  Pivot positions [k1, k2) hold the factor R_B
 // (rb = k2 - k1 rows) of the "B" columns [qB0, qB1); the right-hand side is in l.rhs[column],
 // the pivot position of a column in l.colpos[column] (-1 = unpivoted).
@@ -416,56 +493,15 @@ __device__ inline double ls_solve_reg(int k1, int k2, int qB0, int qB1, int nunp
 	const int pl = l.pivlane[k1 + (act ? lane : 0)];
 	const double rp = sel(act, l.rhs[pl]);  // rhs by pivot position
 	const double inv = sel(act, 1.0 / l.rdiag[k1 + (act ? lane : 0)]);
-	// row `lane` of L = R_B' (pivoted part): L(j, i) = R(i, j) = VR[(k1+j)*LDV + k1+i], i < j
-	double Lrow[NR];
-	{
-		const ldsd *vr = VR + (k1 + (act ? lane : 0)) * LDV + k1;
-#pragma unroll
-		for (int i = 0; i < NR; ++i)
-			Lrow[i] = vr[i];
-#pragma unroll
-		for (int i = 0; i < NR; ++i)
-			pin(Lrow[i]);
-#pragma unroll
-		for (int i = 0; i < NR; ++i)
-			Lrow[i] = sel(act && i < lane, Lrow[i]);
-	}
-	auto fwd = [&](double t) -> double {  // L y = t
-		double acc = t, y = 0.0;
-#pragma unroll
-		for (int i = 0; i < NR; ++i) {
-			if (i >= rb)
-				continue;
-			const double yi = readlane_d(acc * inv, i);
-			y = (lane == i) ? yi : y;
-			acc = fma(-Lrow[i], yi, acc);
-		}
-		return y;
-	};
 	if (nunp == 0) {
-		double q = fwd(rp);
+		double Lrow[NR];
+		load_Lrow(Lrow, k1, rb, l);
+		double q = tri_fwd(Lrow, inv, rp, rb);
 		if (eps != 0.0) {
-			// row `lane` of U = R_B: U(i, j) = R(i, j) = VR[(k1+j)*LDV + k1+i], j > i
 			double Urow[NR];
-#pragma unroll
-			for (int j = 0; j < NR; ++j)
-				Urow[j] = VR[(k1 + (j < rb ? j : 0)) * LDV + k1 + (act ? lane : 0)];
-#pragma unroll
-			for (int j = 0; j < NR; ++j)
-				pin(Urow[j]);
-#pragma unroll
-			for (int j = 0; j < NR; ++j)
-				Urow[j] = sel(act && j > lane && j < rb, Urow[j]);
-			double acc = q, z = 0.0;  // U z = q
-#pragma unroll
-			for (int i = NR - 1; i >= 0; --i) {
-				if (i >= rb)
-					continue;
-				const double zi = readlane_d(acc * inv, i);
-				z = (lane == i) ? zi : z;
-				acc = fma(-Urow[i], zi, acc);
-			}
-			q -= eps * fwd(z);  // (B'B)^-1 q0 = L^-1 U^-1 q0 with B = L, B' = U
+			load_Urow(Urow, k1, rb, l);
+			const double z = tri_bwd(Urow, inv, q, rb);  // U z = q
+			q -= eps * tri_fwd(Lrow, inv, z, rb);	     // (B'B)^-1 q0 = L^-1 U^-1 q0 with B = L, B' = U
 			// residual of the eps-regularised solution: L (q0 - q) = eps z
 			if (res_norm2)
 				*res_norm2 = eps * eps * wave_sum(act ? z * z : 0.0);
@@ -820,6 +856,12 @@ __device__ inline double eqp_step(const SolveArgs &a, const Lds &l, LevelState &
 		}
 	}
 	wave_sync();
+#ifdef HOQP_PROFILE
+	if (a.dbg && lane == 0) {
+		a.dbg[(size_t)blockIdx.x * 16 + 14] += 1;           // EQP calls
+		a.dbg[(size_t)blockIdx.x * 16 + 15] += (nunp > 0);  // ... that needed the semi-normal path
+	}
+#endif
 	double q = ls_solve_reg(k1, k2, w, ncol, nunp, 0.0, ld, nullptr, l);
 	HOQP_STAMP(10);
 	// u = [0 (k1) ; q ; 0],  p = Q u
@@ -850,39 +892,160 @@ __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState 
 	int iters = 0;
 	double level_res2 = 0.0;
 
+	int rank = 0;
+	double yi = 0.0;	 // lane i holds y_i (rotated coordinates)
+	double res_const = 0.0;	 // part of the level residual that no y can change (tall levels)
+	int mB = m;		 // LS rows seen by the active-set loop
+	// A level with more equality rows than free coordinates is first tried "tall": QR of A Z
+	// itself; with full column rank that is the whole answer (unique y, empty null space).
+	// A rank-deficient tall level falls back to the general path (second pass of the loop).
+	bool tall = m > nz && nz > 0;
 	// ---- 1. project the task into the current null space (ConstructH/C/D/FVector,
 	//         ho_qp_problem.cpp:180-285, in factored form) ----
-	{
-		double zc[NR];
-		const ProjLane pl = proj_lane(nz);
-		const ldsd *src = pl.isZ ? l.Z + pl.j : l.x;
-		const int stride = pl.isZ ? ld : 1;
-		const bool live = pl.isZ || pl.isX;
+	auto project = [&](bool doA, bool doD) {
+		{
+			double zc[NR];
+			const ProjLane pl = proj_lane(nz);
+			const ldsd *src = pl.isZ ? l.Z + pl.j : l.x;
+			const int stride = pl.isZ ? ld : 1;
+			const bool live = pl.isZ || pl.isX;
 #pragma unroll
-		for (int i = 0; i < NR; ++i)
-			zc[i] = src[(i < n ? i : 0) * stride];
+			for (int i = 0; i < NR; ++i)
+				zc[i] = src[(i < n ? i : 0) * stride];
 #pragma unroll
-		for (int i = 0; i < NR; ++i)
-			pin(zc[i]);
+			for (int i = 0; i < NR; ++i)
+				pin(zc[i]);
 #pragma unroll
-		for (int i = 0; i < NR; ++i)
-			zc[i] = sel(live && i < n, zc[i]);
-		if (m > 0)
-			project_task(a.A[k] + (size_t)inst * a.m[k] * nstore, a.b[k] + (size_t)inst * a.m[k], m, nstore, n,
-				     nz, ld, zc, true, 0, l);
-		if (p > 0)
-			project_task(a.D[k] + (size_t)inst * a.p[k] * nstore, a.f[k] + (size_t)inst * a.p[k], p, nstore, n,
-				     nz, ld, zc, false, P, l);
-	}
-
+			for (int i = 0; i < NR; ++i)
+				zc[i] = sel(live && i < n, zc[i]);
+			if (m > 0 && doA)
+				project_task(a.A[k] + (size_t)inst * a.m[k] * nstore, a.b[k] + (size_t)inst * a.m[k], m,
+					     nstore, n, nz, ld, zc, true, 0, l);
+			if (p > 0 && doD)
+				project_task(a.D[k] + (size_t)inst * a.p[k] * nstore, a.f[k] + (size_t)inst * a.p[k], p,
+					     nstore, n, nz, ld, zc, false, P, l);
+		}
+	};
+	project(true, true);
 	HOQP_STAMP(1);
-	// ---- 2. complete orthogonal decomposition of A Z (CalcNullSpaceProjMatrix, math.hpp:99-104,
-	//         with an orthonormal Householder basis instead of the FullPivLU kernel) ----
-	int rank = 0;
-	double yi = 0.0;  // lane i holds y_i (rotated coordinates)
-	if (m > 0 && nz > 0) {
+	const bool factorA = m > 0 && nz > 0;
+	if (!factorA && m > 0) {
+		// no free directions left: the residual is what it is
+		const double r = sel(lane < m, l.rhs[lane]);
+		level_res2 = wave_sum(r * r);
+	}
+	if (factorA && tall) {
 		double x[NSP][NT];
 		int pos[NSP];
+		l.colpos[lane] = -1;
+		{
+			// ---- 2t. QR with column pivoting of A Z (m x nz): panel column j < nz is
+			//          coordinate j over the task rows, column nz carries the right-hand side ----
+			const int nslot = (nz + 1 + 15) >> 4;
+#pragma unroll
+			for (int sl = 0; sl < NSP; ++sl) {
+				pos[sl] = -2;
+				if (sl >= nslot)
+					continue;
+				const int q = c + 16 * sl;
+				const bool has = q <= nz;
+				const ldsd *src = (q < nz) ? l.TV + q : l.rhs;
+				const int stride = (q < nz) ? ld : 1;
+#pragma unroll
+				for (int t = 0; t < NT; ++t)
+					x[sl][t] = src[(s + 4 * t) * stride];
+#pragma unroll
+				for (int t = 0; t < NT; ++t)
+					pin(x[sl][t]);
+				t_upto(m, s, [&](int t, bool on) { x[sl][t] = sel(on && has, x[sl][t]); });
+				pos[sl] = has ? -1 : -2;
+			}
+			wave_sync();
+			const int rT = uni(panel_factor(x, pos, nslot, 0, nz, m, 0, kEpsMach * (double)max(m, nz), l));
+			HOQP_STAMP(2);
+			if (rT < nz) {
+				tall = false;  // rank-deficient: project again, then the general path
+			} else {
+			// transformed right-hand side: c1 = entries [0, nz), the rest is the residual
+			if (c == (nz & 15)) {
+#pragma unroll
+				for (int sl = 0; sl < NSP; ++sl) {
+					if (sl != (nz >> 4))
+						continue;
+#pragma unroll
+					for (int t = 0; t < NT; ++t)
+						l.tmp[s + 4 * t] = x[sl][t];
+				}
+			}
+			wave_sync();
+			const double cl = sel(lane < NR, l.tmp[lane & (NR - 1)]);
+			res_const = wave_sum((lane >= nz && lane < m) ? cl * cl : 0.0);
+			rank = nz;
+			if (consider) {
+				// the active-set loop sees the nz compressed rows T Pi' (current coordinates):
+				// BL[p][j] = T(p, pos_j), r0[p] = c1[p]
+				mB = nz;
+#pragma unroll
+				for (int sl = 0; sl < 2; ++sl) {
+					if (16 * sl >= nz)
+						continue;
+					const int pr = c + 16 * sl;
+					const bool hasr = pr < nz;
+					int pj[NT];
+#pragma unroll
+					for (int t = 0; t < NT; ++t)
+						pj[t] = l.colpos[(s + 4 * t < nz) ? s + 4 * t : 0];
+					double dg = l.rdiag[hasr ? pr : 0];
+					double e[NT];
+#pragma unroll
+					for (int t = 0; t < NT; ++t)
+						e[t] = l.TV[(pj[t] > 0 ? pj[t] : 0) * LDV + (hasr ? pr : 0)];
+#pragma unroll
+					for (int t = 0; t < NT; ++t)
+						pin(e[t]);
+					pin(dg);
+					ldsd *row = l.BL + (hasr ? pr : 0) * ld;
+					t_upto(nz, s, [&](int t, bool on) {
+						const double v = (pj[t] > pr) ? e[t] : ((pj[t] == pr) ? dg : 0.0);
+						if (on && hasr)
+							row[s + 4 * t] = v;
+					});
+				}
+				if (lane < nz)
+					l.r0[lane] = cl;
+			} else {
+				// ---- 4t. T z = c1, y = Pi z (+ eps term: z <- z - eps (T'T)^-1 z) ----
+				const bool act = lane < nz;
+				double inv = 1.0 / l.rdiag[act ? lane : 0];
+				inv = sel(act, inv);
+				double Urow[NR];
+				load_Urow(Urow, 0, nz, l);
+				double z = tri_bwd(Urow, inv, sel(act, cl), nz);
+				if (a.eps != 0.0) {
+					double Lrow[NR];
+					load_Lrow(Lrow, 0, nz, l);
+					const double wv = tri_fwd(Lrow, inv, z, nz);
+					z -= a.eps * tri_bwd(Urow, inv, wv, nz);
+				}
+				wave_sync();
+				l.tmp[lane] = z;
+				wave_sync();
+				yi = sel(act, l.tmp[l.colpos[act ? lane : 0] & (kWave - 1)]);
+				level_res2 = res_const;
+			}
+			wave_sync();
+			HOQP_STAMP(3);
+			}
+		}
+		if (!tall)
+			project(true, false);
+	}
+	if (factorA && !tall) {
+		double x[NSP][NT];
+		int pos[NSP];
+		l.colpos[lane] = -1;
+		// ---- 2. complete orthogonal decomposition of A Z (CalcNullSpaceProjMatrix, math.hpp:99-104,
+		//         with an orthonormal Householder basis instead of the FullPivLU kernel) ----
 		const int nslot = (m + 15) >> 4;
 #pragma unroll
 		for (int sl = 0; sl < NSP; ++sl) {
@@ -896,7 +1059,6 @@ __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState 
 			t_upto(nz, s, [&](int t, bool on) { x[sl][t] = sel(on && has, x[sl][t]); });
 			pos[sl] = has ? -1 : -2;
 		}
-		l.colpos[lane] = -1;
 		wave_sync();  // every column is in registers before TV is reused as the reflector store
 		rank = uni(panel_factor(x, pos, nslot, 0, m, nz, 0, kEpsMach * (double)max(m, nz), l));
 		HOQP_STAMP(2);
@@ -967,17 +1129,13 @@ __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState 
 		if (rank > 0)
 			rows_apply_reflectors(l.Z, n, l.G, Pg, ld, nz, 0, rank, l);
 		HOQP_STAMP(4);
-	} else if (m > 0) {
-		// no free directions left: the residual is what it is
-		double r = sel(lane < m, l.rhs[lane]);
-		level_res2 = wave_sum(r * r);
 	}
 
 	if (consider) {
 		// ---- 4b. primal active set on the piecewise quadratic ----
 		if (lane < Pn)
 			l.s[lane] = -l.g[lane];
-		if (lane < m)
+		if (lane < mB)
 			l.rho[lane] = -l.r0[lane];
 		wave_sync();
 		const unsigned long long softmask = (p >= 64) ? ~0ull : (((1ull << p) - 1ull) << P);
@@ -997,7 +1155,7 @@ __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState 
 		bool done = false;
 		for (iters = 0; iters < a.max_iter && !done; ++iters) {
 			const double si = sel(lane < Pn, l.s[lane < Pn ? lane : 0]);
-			const double rj = sel(lane < m, l.rho[lane < m ? lane : 0]);
+			const double rj = sel(lane < mB, l.rho[lane < mB ? lane : 0]);
 			const bool viol = isSoft && si > tolv;
 			const unsigned long long vmask = __ballot(viol);
 			const int nV = __popcll(vmask);
@@ -1006,7 +1164,7 @@ __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState 
 			int k1 = 0;
 			bool overflow = false;
 			HOQP_STAMP(5);
-			const double pi = eqp_step(a, l, st, nz, rank, m, w, nV, &k1, &overflow);
+			const double pi = eqp_step(a, l, st, nz, rank, mB, w, nV, &k1, &overflow);
 			if (overflow) {
 				st.status |= HOQP_STATUS_WORKSPACE;
 				break;
@@ -1022,7 +1180,7 @@ __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState 
 				double gi = 0.0;
 				if (lane < nz) {
 					if (lane < rank)
-						for (int j = 0; j < m; ++j)
+						for (int j = 0; j < mB; ++j)
 							gi = fma(l.BL[j * ld + lane], l.rho[j], gi);
 					unsigned long long mk = vmask;
 					while (mk) {
@@ -1064,10 +1222,10 @@ __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState 
 			l.tmp[lane] = (lane < nz) ? pi : 0.0;
 			wave_sync();
 			rows_dot<4>(l.G, Pn, ld, nz, l.tmp, l.c);
-			rows_dot<2>(l.BL, m, ld, rank, l.tmp, l.a0);
+			rows_dot<2>(l.BL, mB, ld, rank, l.tmp, l.a0);
 			wave_sync();
 			const double ci = sel(lane < Pn, l.c[lane < Pn ? lane : 0]);
-			const double a0 = sel(lane < m, l.a0[lane < m ? lane : 0]);
+			const double a0 = sel(lane < mB, l.a0[lane < mB ? lane : 0]);
 			const double q0 = wave_sum(a0 * rj), q1 = wave_sum(a0 * a0);
 			// ratio test on hard rows outside the working set
 			const bool isHard = lane < P && ((hardmask >> lane) & 1ull) && !((wmask >> lane) & 1ull);
@@ -1121,7 +1279,7 @@ __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState 
 			wave_sync();
 			if (lane < Pn)
 				l.s[lane] = fma(t, ci, si);
-			if (lane < m)
+			if (lane < mB)
 				l.rho[lane] = fma(t, a0, rj);
 			if (t_hard <= t_star && blk >= 0) {
 				if (w < NR) {
@@ -1140,8 +1298,8 @@ __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState 
 		if (!done)
 			st.status |= HOQP_STATUS_MAX_ITER;
 		{
-			double rj = sel(lane < m, l.rho[lane < m ? lane : 0]);
-			level_res2 = wave_sum(rj * rj);
+			double rj = sel(lane < mB, l.rho[lane < mB ? lane : 0]);
+			level_res2 = wave_sum(rj * rj) + res_const;
 		}
 	}
 
