@@ -91,4 +91,53 @@ __device__ __forceinline__ double wave_argmin(double v, int payload, int *idx)
 	return -wave_argmax(-v, payload, idx);
 }
 
+
+// ---------------------------------------------------------------------------
+// cheap pivot search and reciprocal (square) roots for the Householder steps
+// ---------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u(unsigned v)
+{
+	return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+
+// Lane holding the largest 32-bit key, keys identical within a quad, 0 = "not a candidate";
+// -1 if every key is 0.  Ties go to the lowest lane.  Two DPP stages (row_ror:4, row_ror:8)
+// cover the four quads of a 16-lane row, the four rows are merged on the scalar unit.
+__device__ __forceinline__ int wave_argmax_key(unsigned key)
+{
+	unsigned m = key;
+	unsigned t = dpp_u<0x124>(m);
+	m = m > t ? m : t;
+	t = dpp_u<0x128>(m);
+	m = m > t ? m : t;
+	const unsigned m0 = __builtin_amdgcn_readlane(m, 0), m1 = __builtin_amdgcn_readlane(m, 16);
+	const unsigned m2 = __builtin_amdgcn_readlane(m, 32), m3 = __builtin_amdgcn_readlane(m, 48);
+	const unsigned a = m0 > m1 ? m0 : m1, b = m2 > m3 ? m2 : m3;
+	const unsigned mx = a > b ? a : b;
+	if (mx == 0)
+		return -1;
+	const unsigned long long bal = __ballot(key == mx);
+	return __ffsll((long long)bal) - 1;
+}
+
+// 1/sqrt(b) for normal positive b: hardware estimate (~2^-23) + two Newton steps
+__device__ __forceinline__ double fast_rsqrt(double b)
+{
+	double y = __builtin_amdgcn_rsq(b);
+	const double h = 0.5 * b;
+	y = y * fma(-h * y, y, 1.5);
+	y = y * fma(-h * y, y, 1.5);
+	return y;
+}
+
+// 1/d for normal d: hardware estimate + two Newton steps
+__device__ __forceinline__ double fast_rcp(double d)
+{
+	double r = __builtin_amdgcn_rcp(d);
+	r = fma(fma(-d, r, 1.0), r, r);
+	r = fma(fma(-d, r, 1.0), r, r);
+	return r;
+}
+
 }  // namespace hoqp

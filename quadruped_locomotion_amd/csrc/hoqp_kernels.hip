@@ -429,8 +429,8 @@ static int launch_solve(hoqp_handle *h, SolveArgs &a, hipStream_t s)
 	// profiling build: per-section cycle stamps of one launch, printed to stderr
 	unsigned long long *dbg = nullptr;
 	if (getenv("HOQP_DBG") && a.batch > 0) {
-		HIP_OK(h, hipMalloc(&dbg, sizeof(unsigned long long) * 16 * a.batch));
-		HIP_OK(h, hipMemset(dbg, 0, sizeof(unsigned long long) * 16 * a.batch));
+		HIP_OK(h, hipMalloc(&dbg, sizeof(unsigned long long) * 32 * a.batch));
+		HIP_OK(h, hipMemset(dbg, 0, sizeof(unsigned long long) * 32 * a.batch));
 	}
 	a.dbg = dbg;
 	struct Dump {
@@ -443,12 +443,12 @@ static int launch_solve(hoqp_handle *h, SolveArgs &a, hipStream_t s)
 			if (!d)
 				return;
 			(void)hipStreamSynchronize(s);
-			std::vector<unsigned long long> host((size_t)16 * batch);
+			std::vector<unsigned long long> host((size_t)32 * batch);
 			(void)hipMemcpy(host.data(), d, host.size() * 8, hipMemcpyDeviceToHost);
-			double sum[16] = {0};
+			double sum[32] = {0};
 			for (int i = 0; i < batch; ++i)
-				for (int j = 0; j < 16; ++j)
-					sum[j] += (double)host[(size_t)i * 16 + j];
+				for (int j = 0; j < 32; ++j)
+					sum[j] += (double)host[(size_t)i * 32 + j];
 			static const char *nm[16] = {"init", "project", "factor", "ls/bl", "rotate", "qp.misc", "update", "tail",
 						     "eqp.load+W", "eqp.B", "eqp.ls", "eqp.Qp", "qp.mult", "qp.search", "#eqp", "#eqp.csne"};
 			double tot = 0;
@@ -458,6 +458,11 @@ static int launch_solve(hoqp_handle *h, SolveArgs &a, hipStream_t s)
 			for (int j = 0; j < 16; ++j)
 				fprintf(stderr, j < 14 ? " %s=%.0f" : " %s=%.3f", nm[j], sum[j] / batch);
 			fprintf(stderr, " total=%.0f\n", tot / batch);
+			fprintf(stderr, "[hoqp profile] COD factor phases: norms=%.0f argmax=%.0f sqrt=%.0f dump+load=%.0f vv=%.0f apply=%.0f steps=%.2f\n",
+				sum[16] / batch, sum[17] / batch, sum[18] / batch, sum[19] / batch, sum[20] / batch,
+				sum[21] / batch, sum[22] / batch);
+			fprintf(stderr, "[hoqp profile] EQP rank-deficient LS: sum(nunp)=%.3f  #(nunp>4)=%.4f #(nunp>8)=%.4f #(nb>32)=%.4f per instance\n",
+				sum[23] / batch, sum[24] / batch, sum[25] / batch, sum[26] / batch);
 			(void)hipFree(d);
 		}
 	} dump{h, dbg, a.batch, s};

@@ -191,9 +191,27 @@ __device__ __forceinline__ void t_upto(int nr, int s, Body body)
 // remaining candidate column norm is <= rtol * (first pivot norm of this call).  Returns the
 // new step count.
 // ---------------------------------------------------------------------------
-__device__ inline int panel_factor(double (&x)[NSP][NT], int (&pos)[NSP], int nslot, int qlo, int qhi, int nr, int k0,
-				   double rtol, const Lds &l)
+#ifdef HOQP_PROFILE
+#define PF_T(i)                                                       \
+	do {                                                          \
+		unsigned long long n_ = __builtin_amdgcn_s_memtime(); \
+		pt[i] += n_ - t0_;                                    \
+		t0_ = n_;                                             \
+	} while (0)
+#else
+#define PF_T(i) \
+	do {    \
+	} while (0)
+#endif
+
+template <int NS>
+__device__ __forceinline__ int panel_factor_t(double (&x)[NSP][NT], int (&pos)[NSP], int qlo, int qhi, int nr, int k0,
+					      double rtol, const Lds &l, unsigned long long *dbgp)
 {
+#ifdef HOQP_PROFILE
+	unsigned long long pt[7] = {0, 0, 0, 0, 0, 0, 0};
+	unsigned long long t0_ = __builtin_amdgcn_s_memtime();
+#endif
 	const int lane = lane_id(), s = lane & 3, c = lane >> 2;
 	ldsd *VR = l.TV;
 	int k = k0;
@@ -202,9 +220,7 @@ __device__ inline int panel_factor(double (&x)[NSP][NT], int (&pos)[NSP], int ns
 		double best = -1.0;
 		int bq = -1;
 #pragma unroll
-		for (int sl = 0; sl < NSP; ++sl) {
-			if (sl >= nslot)
-				continue;
+		for (int sl = 0; sl < NS; ++sl) {
 			double a0 = 0.0, a1 = 0.0;
 			t_from(k, nr, s, [&](int t, bool on, bool) {
 				const double v = on ? x[sl][t] : 0.0;
@@ -220,21 +236,31 @@ __device__ inline int panel_factor(double (&x)[NSP][NT], int (&pos)[NSP], int ns
 			best = take ? ss : best;
 			bq = take ? q : bq;
 		}
-		int pq;
-		const double bmax = wave_argmax(best, bq, &pq);
-		if (pq < 0 || !(bmax > 0.0))
+		PF_T(0);
+		// pivot = column with the largest key (top 32 bits of the squared norm: any column within
+		// 2^-20 of the largest is as good a pivot); its exact squared norm is read back
+		const int wl = wave_argmax_key(bq >= 0 ? (unsigned)__double2hiint(best) : 0u);
+		if (wl < 0)
 			break;
-		const double nrm = sqrt(bmax);
+		const int pq = __builtin_amdgcn_readlane(bq, wl);
+		const double bmax = readlane_d(best, wl);
+		if (pq < 0 || !(bmax > 1e-290))
+			break;
+		PF_T(1);
+		const double rn = fast_rsqrt(bmax);  // 1 / norm
+		double nrm = bmax * rn;
+		nrm = fma(fma(-nrm, nrm, bmax), 0.5 * rn, nrm);
 		if (first < 0.0)
 			first = nrm;
 		if (!(nrm > rtol * first))
 			break;
+		PF_T(2);
 		const int pc = pq & 15, ps = pq >> 4;
 		ldsd *vr = VR + k * LDV;
 		if (c == pc) {
 #pragma unroll
-			for (int sl = 0; sl < NSP; ++sl) {
-				if (sl != ps)
+			for (int sl = 0; sl < NS; ++sl) {
+				if (NS > 1 && sl != ps)
 					continue;
 				t_upto(nr, s, [&](int t, bool) { vr[s + 4 * t] = x[sl][t]; });
 				pos[sl] = k;
@@ -245,17 +271,17 @@ __device__ inline int panel_factor(double (&x)[NSP][NT], int (&pos)[NSP], int ns
 		double vv[NT];
 		load8(vv, vr + s);
 		pin(alpha);
+		PF_T(3);
 		const double beta = (alpha >= 0.0) ? -nrm : nrm;
 		const double v0 = alpha - beta;
-		const double tk = 1.0 / (nrm * (nrm + fabs(alpha)));
+		const double tk = rn * fast_rcp(nrm + fabs(alpha));  // 2 / v'v = 1 / (nrm (nrm + |alpha|))
 		t_from(k, nr, s, [&](int t, bool on, bool) {
 			const double u = (s + 4 * t == k) ? v0 : vv[t];
 			vv[t] = on ? u : 0.0;
 		});
+		PF_T(4);
 #pragma unroll
-		for (int sl = 0; sl < NSP; ++sl) {
-			if (sl >= nslot)
-				continue;
+		for (int sl = 0; sl < NS; ++sl) {
 			double d0 = 0.0, d1 = 0.0;
 			t_from(k, nr, s, [&](int t, bool, bool) {
 				if (t & 1)
@@ -274,10 +300,30 @@ __device__ inline int panel_factor(double (&x)[NSP][NT], int (&pos)[NSP], int ns
 			l.pivlane[k] = pq;
 			l.colpos[pq] = k;
 		}
+		PF_T(5);
 		++k;
 	}
 	wave_sync();
+#ifdef HOQP_PROFILE
+	if (dbgp && lane == 0) {
+		for (int i = 0; i < 6; ++i)
+			dbgp[16 + i] += pt[i];
+		dbgp[22] += k - k0;
+	}
+#endif
 	return k;
+}
+
+// slot count fixed at compile time inside the step loop (a per-slot scalar branch in every
+// step cost more than the slot's arithmetic); one dispatch per factorization
+__device__ inline int panel_factor(double (&x)[NSP][NT], int (&pos)[NSP], int nslot, int qlo, int qhi, int nr, int k0,
+				   double rtol, const Lds &l, unsigned long long *dbgp = nullptr)
+{
+	if (nslot <= 1)
+		return panel_factor_t<1>(x, pos, qlo, qhi, nr, k0, rtol, l, dbgp);
+	if (nslot == 2)
+		return panel_factor_t<2>(x, pos, qlo, qhi, nr, k0, rtol, l, dbgp);
+	return panel_factor_t<NSP>(x, pos, qlo, qhi, nr, k0, rtol, l, dbgp);
 }
 
 // rows <- rows * H_ka ... H_(kb-1): reflectors [ka, kb) applied from the right to row-major
@@ -464,6 +510,24 @@ __device__ __forceinline__ double tri_bwd(const double (&Urow)[NR], double inv, 
 	return z;
 }
 
+// Solves the (<= 8 x 8) symmetric positive definite system M a = g by Gauss-Jordan without
+// pivoting.  Lane (i, j) = (lane >> 3, lane & 7) holds M(i, j) in mval and g_i in gval; rows
+// beyond the system size hold the identity / 0.  Returns a_(lane >> 3).
+__device__ __forceinline__ double gauss_jordan8(double mval, double gval)
+{
+	const int lane = lane_id(), i = lane >> 3, j = lane & 7;
+#pragma unroll
+	for (int k = 0; k < 8; ++k) {
+		const double rpv = fast_rcp(readlane_d(mval, 9 * k));
+		const double mik = __shfl(mval, i * 8 + k);
+		const double mkj = __shfl(mval, k * 8 + j) * rpv;  // normalised pivot row
+		const double gk = readlane_d(gval, 8 * k) * rpv;
+		mval = (i == k) ? mkj : fma(-mik, mkj, mval);
+		gval = (i == k) ? gk : fma(-mik, gk, gval);
+	}
+	return gval;
+}
+
 // ---------------------------------------------------------------------------
 // Least squares on a finished factorization.  Pivot positions [k1, k2) hold the factor R_B
 // (rb = k2 - k1 rows) of the "B" columns [qB0, qB1); the right-hand side is in l.rhs[column],
@@ -508,6 +572,58 @@ __device__ inline double ls_solve_reg(int k1, int k2, int qB0, int qB1, int nunp
 		} else if (res_norm2) {
 			*res_norm2 = 0.0;
 		}
+		return act ? q : 0.0;
+	}
+
+	if (nunp <= 8) {
+		// ---- rank-deficient B with few dependent columns: the pivoted block R1 (rb x rb) is
+		// nonsingular, the nu unpivoted columns are R1 w_u.  With u = R1' q the problem is
+		//   min |u - d1|^2 + |W'u - d2|^2   =>   u = d1 + W a,  (I + W'W) a = d2 - W'd1,
+		// a nu x nu SPD system (pivots >= 1) solved by an 8 x 8 Gauss-Jordan, one entry per lane.
+		double Lrow[NR], Urow[NR];
+		load_Lrow(Lrow, k1, rb, l);
+		load_Urow(Urow, k1, rb, l);
+		ldsd *Wk = l.X + k1;
+		for (int u = 0; u < nunp; ++u) {  // w_u = R1^-1 r2_u, in place
+			const double r2 = sel(act, Wk[u * ld + (act ? lane : 0)]);
+			const double wv = tri_bwd(Urow, inv, r2, rb);
+			if (act)
+				Wk[u * ld + lane] = wv;
+		}
+		wave_sync();
+		const int gi = lane >> 3, gj = lane & 7;
+		double mval = (gi == gj) ? 1.0 : 0.0, gval = 0.0;
+		for (int u = 0; u < nunp; ++u) {
+			const double wu = sel(act, Wk[u * ld + (act ? lane : 0)]);
+			const double gu = l.rhs[l.xlane[u]] - wave_sum(wu * rp);
+			gval = (gi == u) ? gu : gval;
+			for (int v = 0; v <= u; ++v) {
+				const double wv = sel(act, Wk[v * ld + (act ? lane : 0)]);
+				const double mv = wave_sum(wu * wv) + ((u == v) ? 1.0 : 0.0);
+				mval = (lane == u * 8 + v || lane == v * 8 + u) ? mv : mval;
+			}
+		}
+		const double av = gauss_jordan8(mval, gval);  // a_(lane >> 3)
+		double e = 0.0;
+		for (int u = 0; u < nunp; ++u)
+			e = fma(readlane_d(av, 8 * u), sel(act, Wk[u * ld + (act ? lane : 0)]), e);
+		double q = tri_fwd(Lrow, inv, rp + e, rb);
+		if (res_norm2)  // |u - d1|^2 + |W'u - d2|^2 = |e|^2 + |a|^2
+			*res_norm2 = wave_sum(e * e) + wave_sum(gj == 0 ? av * av : 0.0);
+		if (eps != 0.0) {
+			// q <- q - eps (R_B R_B')^-1 q,  (R_B R_B')^-1 = R1^-T (I - W (I + W'W)^-1 W') R1^-1
+			double z = tri_bwd(Urow, inv, q, rb);
+			double hval = 0.0;
+			for (int u = 0; u < nunp; ++u) {
+				const double hu = wave_sum(sel(act, Wk[u * ld + (act ? lane : 0)]) * z);
+				hval = (gi == u) ? hu : hval;
+			}
+			const double bv = gauss_jordan8(mval, hval);
+			for (int u = 0; u < nunp; ++u)
+				z = fma(-readlane_d(bv, 8 * u), sel(act, Wk[u * ld + (act ? lane : 0)]), z);
+			q -= eps * tri_fwd(Lrow, inv, z, rb);
+		}
+		wave_sync();
 		return act ? q : 0.0;
 	}
 
@@ -747,13 +863,19 @@ __device__ inline void project_task(const double *__restrict__ rows_g, const dou
 	do {                                                                          \
 		unsigned long long now_ = __builtin_amdgcn_s_memtime();               \
 		if (a.dbg && lane_id() == 0)                                          \
-			a.dbg[(size_t)blockIdx.x * 16 + (slot)] += now_ - st.t_last;  \
+			a.dbg[(size_t)blockIdx.x * 32 + (slot)] += now_ - st.t_last;  \
 		st.t_last = __builtin_amdgcn_s_memtime();                             \
 	} while (0)
 #else
 #define HOQP_STAMP(slot) \
 	do {             \
 	} while (0)
+#endif
+
+#ifdef HOQP_PROFILE
+#define HOQP_DBGP (a.dbg ? a.dbg + (size_t)blockIdx.x * 32 : nullptr)
+#else
+#define HOQP_DBGP nullptr
 #endif
 
 struct LevelState {
@@ -858,8 +980,12 @@ __device__ inline double eqp_step(const SolveArgs &a, const Lds &l, LevelState &
 	wave_sync();
 #ifdef HOQP_PROFILE
 	if (a.dbg && lane == 0) {
-		a.dbg[(size_t)blockIdx.x * 16 + 14] += 1;           // EQP calls
-		a.dbg[(size_t)blockIdx.x * 16 + 15] += (nunp > 0);  // ... that needed the semi-normal path
+		a.dbg[(size_t)blockIdx.x * 32 + 14] += 1;           // EQP calls
+		a.dbg[(size_t)blockIdx.x * 32 + 15] += (nunp > 0);  // ... that needed the semi-normal path
+		a.dbg[(size_t)blockIdx.x * 32 + 23] += nunp;
+		a.dbg[(size_t)blockIdx.x * 32 + 24] += (nunp > 4);
+		a.dbg[(size_t)blockIdx.x * 32 + 25] += (nunp > 8);
+		a.dbg[(size_t)blockIdx.x * 32 + 26] += (nunp > 0 && k2 - k1 + nunp > 32);
 	}
 #endif
 	double q = ls_solve_reg(k1, k2, w, ncol, nunp, 0.0, ld, nullptr, l);
@@ -961,7 +1087,7 @@ __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState 
 				pos[sl] = has ? -1 : -2;
 			}
 			wave_sync();
-			const int rT = uni(panel_factor(x, pos, nslot, 0, nz, m, 0, kEpsMach * (double)max(m, nz), l));
+			const int rT = uni(panel_factor(x, pos, nslot, 0, nz, m, 0, kEpsMach * (double)max(m, nz), l, HOQP_DBGP));
 			HOQP_STAMP(2);
 			if (rT < nz) {
 				tall = false;  // rank-deficient: project again, then the general path
@@ -1060,7 +1186,7 @@ __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState 
 			pos[sl] = has ? -1 : -2;
 		}
 		wave_sync();  // every column is in registers before TV is reused as the reflector store
-		rank = uni(panel_factor(x, pos, nslot, 0, m, nz, 0, kEpsMach * (double)max(m, nz), l));
+		rank = uni(panel_factor(x, pos, nslot, 0, m, nz, 0, kEpsMach * (double)max(m, nz), l, HOQP_DBGP));
 		HOQP_STAMP(2);
 		int nunp = 0;
 		int uidx[NSP];
