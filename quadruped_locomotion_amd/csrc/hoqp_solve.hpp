@@ -329,8 +329,9 @@ __device__ inline int panel_factor(double (&x)[NSP][NT], int (&pos)[NSP], int ns
 // rows <- rows * H_ka ... H_(kb-1): reflectors [ka, kb) applied from the right to row-major
 // rows.  Row r = c + 16*slot is a vector owned by quad c; rows r < n0 come from A0, the rest
 // from A1.
-__device__ inline void rows_apply_reflectors(ldsd *A0, int n0, ldsd *A1, int n1, int ldr, int nr, int ka, int kb,
-					     const Lds &l)
+template <int NS>
+__device__ __forceinline__ void rows_apply_reflectors_t(ldsd *A0, int n0, ldsd *A1, int n1, int ldr, int nr, int ka,
+							int kb, const Lds &l)
 {
 	const int lane = lane_id(), s = lane & 3, c = lane >> 2;
 	const int R = n0 + n1;
@@ -343,9 +344,7 @@ __device__ inline void rows_apply_reflectors(ldsd *A0, int n0, ldsd *A1, int n1,
 	ldsd *rowp[NSR];
 	bool valid[NSR];
 #pragma unroll
-	for (int sl = 0; sl < NSR; ++sl) {
-		if (16 * sl >= R)
-			continue;
+	for (int sl = 0; sl < NS; ++sl) {
 		const int r = c + 16 * sl;
 		valid[sl] = r < R;
 		const int rr = valid[sl] ? r : 0;
@@ -361,9 +360,7 @@ __device__ inline void rows_apply_reflectors(ldsd *A0, int n0, ldsd *A1, int n1,
 		pin(tk);
 		t_from(k, nr, s, [&](int t, bool on, bool) { vv[t] = sel(on, vv[t]); });
 #pragma unroll
-		for (int sl = 0; sl < NSR; ++sl) {
-			if (16 * sl >= R)
-				continue;
+		for (int sl = 0; sl < NS; ++sl) {
 			double d0 = 0.0, d1 = 0.0;
 			t_from(k, nr, s, [&](int t, bool, bool) {
 				if (t & 1)
@@ -376,15 +373,26 @@ __device__ inline void rows_apply_reflectors(ldsd *A0, int n0, ldsd *A1, int n1,
 		}
 	}
 #pragma unroll
-	for (int sl = 0; sl < NSR; ++sl) {
-		if (16 * sl >= R)
-			continue;
+	for (int sl = 0; sl < NS; ++sl) {
 		t_upto(nr, s, [&](int t, bool on) {
 			if (on && valid[sl])
 				rowp[sl][s + 4 * t] = x[sl][t];
 		});
 	}
 	wave_sync();
+}
+
+// slot count fixed at compile time (see panel_factor)
+__device__ inline void rows_apply_reflectors(ldsd *A0, int n0, ldsd *A1, int n1, int ldr, int nr, int ka, int kb,
+					     const Lds &l)
+{
+	const int R = n0 + n1;
+	if (R <= 32)
+		rows_apply_reflectors_t<2>(A0, n0, A1, n1, ldr, nr, ka, kb, l);
+	else if (R <= 64)
+		rows_apply_reflectors_t<4>(A0, n0, A1, n1, ldr, nr, ka, kb, l);
+	else
+		rows_apply_reflectors_t<NSR>(A0, n0, A1, n1, ldr, nr, ka, kb, l);
 }
 
 // out[r] = rows[r][0..nr) . vec[0..nr) for r < R (row r owned by quad r & 15, slot r >> 4)
@@ -999,6 +1007,53 @@ __device__ inline double eqp_step(const SolveArgs &a, const Lds &l, LevelState &
 	return pi;
 }
 
+// Level update on the rows of Z and G (row r = c + 16*slot):  d_r = row_r . y  -> l.S[r], then
+// the rows lose their first `rank` coordinates (shifted store).  y is in l.tmp.
+template <int NS>
+__device__ __forceinline__ void level_update_t(const Lds &l, int n, int Pg, int nz, int rank, int ld)
+{
+	const int lane = lane_id(), s = lane & 3, c = lane >> 2;
+	const int R = n + Pg;
+	double yv[NT];
+	load8(yv, l.tmp + s);
+	t_upto(nz, s, [&](int t, bool on) { yv[t] = sel(on, yv[t]); });
+	double x[NS][NT];
+	ldsd *rowp[NS];
+	bool valid[NS];
+	// every load of every slot precedes the first shifted store (single wavefront, LDS in order)
+#pragma unroll
+	for (int sl = 0; sl < NS; ++sl) {
+		const int r = c + 16 * sl;
+		valid[sl] = r < R;
+		const int rr = valid[sl] ? r : 0;
+		rowp[sl] = (rr < n) ? l.Z + rr * ld : l.G + (rr - n) * ld;
+		load8(x[sl], rowp[sl] + s);
+	}
+#pragma unroll
+	for (int sl = 0; sl < NS; ++sl) {
+		double d0 = 0.0, d1 = 0.0;
+		t_upto(nz, s, [&](int t, bool on) {
+			x[sl][t] = sel(on, x[sl][t]);
+			if (t & 1)
+				d1 = fma(x[sl][t], yv[t], d1);
+			else
+				d0 = fma(x[sl][t], yv[t], d0);
+		});
+		const double d = quad_sum(d0 + d1);
+		if (valid[sl] && s == 0)
+			l.S[c + 16 * sl] = d;
+	}
+	if (rank > 0 && rank < nz) {
+#pragma unroll
+		for (int sl = 0; sl < NS; ++sl) {
+			t_from(rank, nz, s, [&](int t, bool on, bool) {
+				if (on && valid[sl] && s + 4 * t < nz)
+					rowp[sl][s + 4 * t - rank] = x[sl][t];
+			});
+		}
+	}
+}
+
 // ---------------------------------------------------------------------------
 // one priority level (HoQpProblem constructor pipeline, ho_qp_problem.cpp:11-25)
 // ---------------------------------------------------------------------------
@@ -1437,62 +1492,25 @@ __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState 
 	wave_sync();
 	{
 		const int R = n + Pg;
-		double yv[NT];
-		load8(yv, l.tmp + s);
-		t_upto(nz, s, [&](int t, bool on) { yv[t] = sel(on, yv[t]); });
-		double x[NSR][NT];
-		double dd[NSR];
-		// every load of every slot precedes the first shifted store (single wavefront, LDS in order)
-#pragma unroll
-		for (int sl = 0; sl < NSR; ++sl) {
-			if (16 * sl >= R)
-				continue;
-			const int r = c + 16 * sl;
-			const int rr = (r < R) ? r : 0;
-			const ldsd *rowp = (rr < n) ? l.Z + rr * ld : l.G + (rr - n) * ld;
-			double d0 = 0.0, d1 = 0.0;
-			load8(x[sl], rowp + s);
-			t_upto(nz, s, [&](int t, bool on) {
-				x[sl][t] = sel(on, x[sl][t]);
-				if (t & 1)
-					d1 = fma(x[sl][t], yv[t], d1);
-				else
-					d0 = fma(x[sl][t], yv[t], d0);
-			});
-			dd[sl] = quad_sum(d0 + d1);
-		}
+		if (R <= 32)
+			level_update_t<2>(l, n, Pg, nz, rank, ld);
+		else if (R <= 64)
+			level_update_t<4>(l, n, Pg, nz, rank, ld);
+		else
+			level_update_t<NSR>(l, n, Pg, nz, rank, ld);
 		wave_sync();
-#pragma unroll
-		for (int sl = 0; sl < NSR; ++sl) {
-			if (16 * sl >= R)
-				continue;
-			const int r = c + 16 * sl;
-			const bool valid = r < R;
-			const int rr = valid ? r : 0;
-			const bool isZ = rr < n;
-			ldsd *rowp = isZ ? l.Z + rr * ld : l.G + (rr - n) * ld;
-			const double d = dd[sl];
-			if (valid && s == 0) {
-				if (isZ) {
-					l.x[rr] += d;
-				} else {
-					const int gr = rr - n;
-					double gi = l.g[gr] - d;
-					if (gr >= P) {
-						// v* = (D x - f)_+ ; the row becomes hard with rhs f + v* - D x
-						if (a.out.v)
-							a.out.v[(size_t)inst * a.Ptot + st.Pout + (gr - P)] = fmax(0.0, -gi);
-						gi = fmax(gi, 0.0);
-					}
-					l.g[gr] = gi;
-				}
+		// one row per lane: x += (Z y), g -= (G y) with the slack bookkeeping of this level's rows
+		if (lane < n)
+			l.x[lane] += l.S[lane];
+		if (lane < Pg) {
+			double gi = l.g[lane] - l.S[n + lane];
+			if (lane >= P) {
+				// v* = (D x - f)_+ ; the row becomes hard with rhs f + v* - D x
+				if (a.out.v)
+					a.out.v[(size_t)inst * a.Ptot + st.Pout + (lane - P)] = fmax(0.0, -gi);
+				gi = fmax(gi, 0.0);
 			}
-			if (rank > 0 && valid) {
-				t_from(rank, nz, s, [&](int t, bool on, bool) {
-					if (on && s + 4 * t < nz)
-						rowp[s + 4 * t - rank] = x[sl][t];
-				});
-			}
+			l.g[lane] = gi;
 		}
 	}
 	if (lane == 0) {
