@@ -461,6 +461,7 @@ static int launch_solve(hoqp_handle *h, SolveArgs &a, hipStream_t s)
 			fprintf(stderr, "[hoqp profile] COD factor phases: norms=%.0f argmax=%.0f sqrt=%.0f dump+load=%.0f vv=%.0f apply=%.0f steps=%.2f\n",
 				sum[16] / batch, sum[17] / batch, sum[18] / batch, sum[19] / batch, sum[20] / batch,
 				sum[21] / batch, sum[22] / batch);
+			fprintf(stderr, "[hoqp profile] update parts: rows=%.0f of which issue=%.0f wait=%.0f dots=%.0f stores=%.0f\n", sum[27] / batch, sum[28] / batch, sum[29] / batch, sum[30] / batch, sum[31] / batch);
 			fprintf(stderr, "[hoqp profile] EQP rank-deficient LS: sum(nunp)=%.3f  #(nunp>4)=%.4f #(nunp>8)=%.4f #(nb>32)=%.4f per instance\n",
 				sum[23] / batch, sum[24] / batch, sum[25] / batch, sum[26] / batch);
 			(void)hipFree(d);

@@ -46,7 +46,7 @@ struct SolveArgs {
 
 // byte offsets of the LDS arrays (shared by host sizing and device addressing)
 struct LdsOff {
-	int Z, x, G, g, s, c, TV, S, BL, r0, rho, a0, tau, rdiag, rhs, X, tmp, pivlane, W, xlane, colpos, vlist, total;
+	int Z, x, G, g, s, c, TV, S, BL, r0, rho, a0, tau, rdiag, rhs, X, tmp, dump, pivlane, W, xlane, colpos, vlist, total;
 };
 
 __host__ __device__ inline LdsOff lds_offsets(const SolveArgs &a)
@@ -77,6 +77,7 @@ __host__ __device__ inline LdsOff lds_offsets(const SolveArgs &a)
 	o.rhs = take(8 * kWave);
 	o.X = o.S;  // the staging buffer is dead whenever X is live
 	o.tmp = take(8 * kWave);
+	o.dump = take(8 * kWave);  // per-lane sink of predicated-off stores
 	o.pivlane = take(4 * NR);
 	o.W = take(4 * NR);
 	o.xlane = take(4 * XROWS);
@@ -88,7 +89,7 @@ __host__ __device__ inline LdsOff lds_offsets(const SolveArgs &a)
 
 #ifdef __HIP_DEVICE_COMPILE__
 struct Lds {
-	ldsd *Z, *x, *G, *g, *s, *c, *TV, *S, *BL, *r0, *rho, *a0, *tau, *rdiag, *rhs, *X, *tmp;
+	ldsd *Z, *x, *G, *g, *s, *c, *TV, *S, *BL, *r0, *rho, *a0, *tau, *rdiag, *rhs, *X, *tmp, *dump;
 	ldsi *pivlane, *W, *xlane, *colpos, *vlist;
 };
 
@@ -113,6 +114,7 @@ __device__ inline Lds lds_bind(const SolveArgs &a, HOQP_LDS char *base)
 	l.rhs = (ldsd *)(base + o.rhs);
 	l.X = (ldsd *)(base + o.X);
 	l.tmp = (ldsd *)(base + o.tmp);
+	l.dump = (ldsd *)(base + o.dump);
 	l.pivlane = (ldsi *)(base + o.pivlane);
 	l.W = (ldsi *)(base + o.W);
 	l.xlane = (ldsi *)(base + o.xlane);
@@ -127,6 +129,15 @@ __device__ inline Lds lds_bind(const SolveArgs &a, HOQP_LDS char *base)
 // that are read to their full NR extent.
 __device__ __forceinline__ double sel(bool on, double v) { return on ? v : 0.0; }
 
+// Predicated LDS store without touching EXEC: a store behind `if (on)` costs an exec save /
+// restore pair around every ds_write (measured ~60 cycles each); instead the address of a
+// masked-off lane is redirected to that lane's private sink slot.
+__device__ __forceinline__ void st_if(bool on, ldsd *p, ldsd *sink, double v)
+{
+	ldsd *q = on ? p : sink;
+	*q = v;
+}
+
 // Pins a loaded value in a register.  Without it the compiler turns `cond ? load : 0` back
 // into a branch around the load (select-with-load -> branch in CodeGenPrepare), which
 // serialises the loads: exec-mask juggling plus one s_waitcnt per element.  Always load a
@@ -135,14 +146,26 @@ __device__ __forceinline__ void pin(double &v) { asm volatile("" : "+v"(v)); }
 
 // u[t] = p[4 t], t < NT: one lane's entries of a vector stored with unit stride
 // (p already includes the lane's entry offset s)
-__device__ __forceinline__ void load8(double (&u)[NT], const ldsd *p)
+__device__ __forceinline__ void ld8(double (&u)[NT], const ldsd *p)
 {
 #pragma unroll
 	for (int t = 0; t < NT; ++t)
 		u[t] = p[4 * t];
+}
+
+__device__ __forceinline__ void pin8(double (&u)[NT])
+{
 #pragma unroll
 	for (int t = 0; t < NT; ++t)
 		pin(u[t]);
+}
+
+// single group: loads then pins.  Several groups: ld8 every group first, then pin8 every group
+// (a pin waits for its load, so pinning group 0 before loading group 1 costs a round trip).
+__device__ __forceinline__ void load8(double (&u)[NT], const ldsd *p)
+{
+	ld8(u, p);
+	pin8(u);
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -349,9 +372,14 @@ __device__ __forceinline__ void rows_apply_reflectors_t(ldsd *A0, int n0, ldsd *
 		valid[sl] = r < R;
 		const int rr = valid[sl] ? r : 0;
 		rowp[sl] = (rr < n0) ? A0 + rr * ldr : A1 + (rr - n0) * ldr;
-		load8(x[sl], rowp[sl] + s);
-		t_upto(nr, s, [&](int t, bool on) { x[sl][t] = sel(on && valid[sl], x[sl][t]); });
+		ld8(x[sl], rowp[sl] + s);
 	}
+#pragma unroll
+	for (int sl = 0; sl < NS; ++sl)
+		pin8(x[sl]);
+#pragma unroll
+	for (int sl = 0; sl < NS; ++sl)
+		t_upto(nr, s, [&](int t, bool on) { x[sl][t] = sel(on && valid[sl], x[sl][t]); });
 	for (int k = ka; k < kb; ++k) {
 		const ldsd *vr = VR + k * LDV;
 		double tk = l.tau[k];
@@ -374,10 +402,7 @@ __device__ __forceinline__ void rows_apply_reflectors_t(ldsd *A0, int n0, ldsd *
 	}
 #pragma unroll
 	for (int sl = 0; sl < NS; ++sl) {
-		t_upto(nr, s, [&](int t, bool on) {
-			if (on && valid[sl])
-				rowp[sl][s + 4 * t] = x[sl][t];
-		});
+		t_upto(nr, s, [&](int t, bool on) { st_if(on && valid[sl], rowp[sl] + (s + 4 * t), l.dump + lane, x[sl][t]); });
 	}
 	wave_sync();
 }
@@ -403,27 +428,31 @@ __device__ inline void rows_dot(const ldsd *A, int R, int ldr, int nr, const lds
 	if (R <= 0)
 		return;
 	double vv[NT];
-	load8(vv, vec + s);
+	double ev[NS][NT];
+	ld8(vv, vec + s);
+#pragma unroll
+	for (int sl = 0; sl < NS; ++sl) {
+		const int r = c + 16 * sl;
+		ld8(ev[sl], A + (r < R ? r : 0) * ldr + s);
+	}
+	pin8(vv);
+#pragma unroll
+	for (int sl = 0; sl < NS; ++sl)
+		pin8(ev[sl]);
 	t_upto(nr, s, [&](int t, bool on) { vv[t] = sel(on, vv[t]); });
 #pragma unroll
 	for (int sl = 0; sl < NS; ++sl) {
-		if (16 * sl >= R)
-			continue;
 		const int r = c + 16 * sl;
-		const bool valid = r < R;
-		const ldsd *rowp = A + (valid ? r : 0) * ldr;
 		double d0 = 0.0, d1 = 0.0;
-		double ev[NT];
-		load8(ev, rowp + s);
 		t_upto(nr, s, [&](int t, bool on) {
-			const double e = sel(on, ev[t]);
+			const double e = sel(on, ev[sl][t]);
 			if (t & 1)
 				d1 = fma(e, vv[t], d1);
 			else
 				d0 = fma(e, vv[t], d0);
 		});
 		const double d = quad_sum(d0 + d1);
-		if (valid && s == 0)
+		if (r < R && s == 0)
 			out[r] = d;
 	}
 }
@@ -839,28 +868,36 @@ __device__ inline void project_task(const double *__restrict__ rows_g, const dou
 			double a0 = 0.0, a1 = 0.0;
 			// all 16 reads are issued back to back (one LDS round trip per row pair); entries
 			// >= n multiply zc == 0
+			double te[NR];
 #pragma unroll
 			for (int e = 0; e < NR; e += 2) {
 				const d2v t = sr2[e >> 1];
-				a0 = fma(t.x, zc[e], a0);
-				a1 = fma(t.y, zc[e + 1], a1);
+				te[e] = t.x;
+				te[e + 1] = t.y;
+			}
+#pragma unroll
+			for (int e = 0; e < NR; ++e)
+				pin(te[e]);
+#pragma unroll
+			for (int e = 0; e < NR; e += 2) {
+				a0 = fma(te[e], zc[e], a0);
+				a1 = fma(te[e + 1], zc[e + 1], a1);
 			}
 			const double acc = a0 + a1;
 			const int ra = pl.dual ? 2 * i : i;
 			const double rrA = readlane_d(rv, ra), rrB = readlane_d(rv, (ra + 1) & 63);
 			const double rr = (pl.dual && h) ? rrB : rrA;
 			const bool rok = r < nr;
+			// one store per lane: the projected entry, the right-hand side, or the sink
+			ldsd *dst = l.dump + lane;
 			if (to_T) {
-				if (pl.isZ && rok)
-					l.TV[(r0 + r) * ld + pl.j] = acc;
-				if (pl.isX && rok)
-					l.rhs[r0 + r] = rr - acc;
+				dst = (pl.isZ && rok) ? l.TV + (r0 + r) * ld + pl.j : dst;
+				dst = (pl.isX && rok) ? l.rhs + (r0 + r) : dst;
 			} else {
-				if (pl.isZ && rok)
-					l.G[(P + r0 + r) * ld + pl.j] = acc;
-				if (pl.isX && rok)
-					l.g[P + r0 + r] = rr - acc;
+				dst = (pl.isZ && rok) ? l.G + (P + r0 + r) * ld + pl.j : dst;
+				dst = (pl.isX && rok) ? l.g + (P + r0 + r) : dst;
 			}
+			*dst = pl.isX ? rr - acc : acc;
 		}
 	}
 	wave_sync();
@@ -924,11 +961,12 @@ __device__ inline double eqp_step(const SolveArgs &a, const Lds &l, LevelState &
 	}
 	const int nslot = (ncol + 15) >> 4;
 	double x[NSP][NT];
-	int pos[NSP];
+	int pos[NSP], lims[NSP];
 	wave_sync();
 #pragma unroll
 	for (int sl = 0; sl < NSP; ++sl) {
 		pos[sl] = -2;
+		lims[sl] = 0;
 		if (sl >= nslot)
 			continue;
 		const int q = c + 16 * sl;
@@ -938,10 +976,16 @@ __device__ inline double eqp_step(const SolveArgs &a, const Lds &l, LevelState &
 		const int vq = l.vlist[(has && !isW && !isL) ? q - w - m : 0];
 		const int grow = has ? (isW ? wq : (isL ? 0 : vq)) : 0;
 		const ldsd *src = isL ? l.BL + (q - w) * ld : l.G + grow * ld;
-		const int lim = isL ? rank : nz;
-		load8(x[sl], src + s);
-		t_upto(nz, s, [&](int t, bool) { x[sl][t] = sel(has && s + 4 * t < lim, x[sl][t]); });
+		lims[sl] = has ? (isL ? rank : nz) : 0;
+		ld8(x[sl], src + s);
 		pos[sl] = has ? -1 : -2;
+	}
+#pragma unroll
+	for (int sl = 0; sl < NSP; ++sl) {
+		if (sl >= nslot)
+			continue;
+		pin8(x[sl]);
+		t_upto(nz, s, [&](int t, bool) { x[sl][t] = sel(s + 4 * t < lims[sl], x[sl][t]); });
 	}
 	{
 		// right-hand side and pivot map per column (lane == column)
@@ -1010,13 +1054,17 @@ __device__ inline double eqp_step(const SolveArgs &a, const Lds &l, LevelState &
 // Level update on the rows of Z and G (row r = c + 16*slot):  d_r = row_r . y  -> l.S[r], then
 // the rows lose their first `rank` coordinates (shifted store).  y is in l.tmp.
 template <int NS>
-__device__ __forceinline__ void level_update_t(const Lds &l, int n, int Pg, int nz, int rank, int ld)
+__device__ __forceinline__ void level_update_t(const Lds &l, int n, int Pg, int nz, int rank, int ld,
+					       unsigned long long *dbgp = nullptr)
 {
 	const int lane = lane_id(), s = lane & 3, c = lane >> 2;
+#ifdef HOQP_PROFILE
+	unsigned long long pt[4] = {0, 0, 0, 0};
+	unsigned long long t0_ = __builtin_amdgcn_s_memtime();
+#endif
 	const int R = n + Pg;
 	double yv[NT];
-	load8(yv, l.tmp + s);
-	t_upto(nz, s, [&](int t, bool on) { yv[t] = sel(on, yv[t]); });
+	ld8(yv, l.tmp + s);
 	double x[NS][NT];
 	ldsd *rowp[NS];
 	bool valid[NS];
@@ -1027,8 +1075,15 @@ __device__ __forceinline__ void level_update_t(const Lds &l, int n, int Pg, int 
 		valid[sl] = r < R;
 		const int rr = valid[sl] ? r : 0;
 		rowp[sl] = (rr < n) ? l.Z + rr * ld : l.G + (rr - n) * ld;
-		load8(x[sl], rowp[sl] + s);
+		ld8(x[sl], rowp[sl] + s);
 	}
+	PF_T(0);
+	pin8(yv);
+#pragma unroll
+	for (int sl = 0; sl < NS; ++sl)
+		pin8(x[sl]);
+	PF_T(1);
+	t_upto(nz, s, [&](int t, bool on) { yv[t] = sel(on, yv[t]); });
 #pragma unroll
 	for (int sl = 0; sl < NS; ++sl) {
 		double d0 = 0.0, d1 = 0.0;
@@ -1043,15 +1098,21 @@ __device__ __forceinline__ void level_update_t(const Lds &l, int n, int Pg, int 
 		if (valid[sl] && s == 0)
 			l.S[c + 16 * sl] = d;
 	}
+	PF_T(2);
 	if (rank > 0 && rank < nz) {
 #pragma unroll
 		for (int sl = 0; sl < NS; ++sl) {
 			t_from(rank, nz, s, [&](int t, bool on, bool) {
-				if (on && valid[sl] && s + 4 * t < nz)
-					rowp[sl][s + 4 * t - rank] = x[sl][t];
+				st_if(on && valid[sl] && s + 4 * t < nz, rowp[sl] + (s + 4 * t - rank), l.dump + lane, x[sl][t]);
 			});
 		}
 	}
+	PF_T(3);
+#ifdef HOQP_PROFILE
+	if (dbgp && lane == 0)
+		for (int i = 0; i < 4; ++i)
+			dbgp[28 + i] += pt[i];
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -1135,11 +1196,14 @@ __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState 
 #pragma unroll
 				for (int t = 0; t < NT; ++t)
 					x[sl][t] = src[(s + 4 * t) * stride];
-#pragma unroll
-				for (int t = 0; t < NT; ++t)
-					pin(x[sl][t]);
-				t_upto(m, s, [&](int t, bool on) { x[sl][t] = sel(on && has, x[sl][t]); });
 				pos[sl] = has ? -1 : -2;
+			}
+#pragma unroll
+			for (int sl = 0; sl < NSP; ++sl) {
+				if (sl >= nslot)
+					continue;
+				pin8(x[sl]);
+				t_upto(m, s, [&](int t, bool on) { x[sl][t] = sel(on && pos[sl] == -1, x[sl][t]); });
 			}
 			wave_sync();
 			const int rT = uni(panel_factor(x, pos, nslot, 0, nz, m, 0, kEpsMach * (double)max(m, nz), l, HOQP_DBGP));
@@ -1236,9 +1300,15 @@ __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState 
 			const int q = c + 16 * sl;
 			const bool has = q < m;
 			const ldsd *src = l.TV + (has ? q : 0) * ld;
-			load8(x[sl], src + s);
-			t_upto(nz, s, [&](int t, bool on) { x[sl][t] = sel(on && has, x[sl][t]); });
+			ld8(x[sl], src + s);
 			pos[sl] = has ? -1 : -2;
+		}
+#pragma unroll
+		for (int sl = 0; sl < NSP; ++sl) {
+			if (sl >= nslot)
+				continue;
+			pin8(x[sl]);
+			t_upto(nz, s, [&](int t, bool on) { x[sl][t] = sel(on && pos[sl] == -1, x[sl][t]); });
 		}
 		wave_sync();  // every column is in registers before TV is reused as the reflector store
 		rank = uni(panel_factor(x, pos, nslot, 0, m, nz, 0, kEpsMach * (double)max(m, nz), l, HOQP_DBGP));
@@ -1493,12 +1563,13 @@ __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState 
 	{
 		const int R = n + Pg;
 		if (R <= 32)
-			level_update_t<2>(l, n, Pg, nz, rank, ld);
+			level_update_t<2>(l, n, Pg, nz, rank, ld, HOQP_DBGP);
 		else if (R <= 64)
-			level_update_t<4>(l, n, Pg, nz, rank, ld);
+			level_update_t<4>(l, n, Pg, nz, rank, ld, HOQP_DBGP);
 		else
-			level_update_t<NSR>(l, n, Pg, nz, rank, ld);
+			level_update_t<NSR>(l, n, Pg, nz, rank, ld, HOQP_DBGP);
 		wave_sync();
+		HOQP_STAMP(27);
 		// one row per lane: x += (Z y), g -= (G y) with the slack bookkeeping of this level's rows
 		if (lane < n)
 			l.x[lane] += l.S[lane];
