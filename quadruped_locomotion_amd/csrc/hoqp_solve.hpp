@@ -482,15 +482,25 @@ __device__ __forceinline__ void load_Lrow(double (&Lrow)[NR], int k1, int rb, co
 	const int lane = lane_id();
 	const bool act = lane < rb;
 	const ldsd *vr = l.TV + (k1 + (act ? lane : 0)) * LDV + k1;
+	// only the blocks of 8 below rb are loaded and masked (one scalar branch per block)
 #pragma unroll
-	for (int i = 0; i < NR; ++i)
-		Lrow[i] = vr[i];
+	for (int b = 0; b < NR / 8; ++b) {
+		if (8 * b >= rb) {
 #pragma unroll
-	for (int i = 0; i < NR; ++i)
-		pin(Lrow[i]);
+			for (int i = 8 * b; i < 8 * b + 8; ++i)
+				Lrow[i] = 0.0;
+			continue;
+		}
 #pragma unroll
-	for (int i = 0; i < NR; ++i)
-		Lrow[i] = sel(act && i < lane, Lrow[i]);
+		for (int i = 8 * b; i < 8 * b + 8; ++i)
+			Lrow[i] = vr[i];
+#pragma unroll
+		for (int i = 8 * b; i < 8 * b + 8; ++i)
+			pin(Lrow[i]);
+#pragma unroll
+		for (int i = 8 * b; i < 8 * b + 8; ++i)
+			Lrow[i] = sel(act && i < lane, Lrow[i]);
+	}
 }
 
 __device__ __forceinline__ void load_Urow(double (&Urow)[NR], int k1, int rb, const Lds &l)
@@ -499,14 +509,23 @@ __device__ __forceinline__ void load_Urow(double (&Urow)[NR], int k1, int rb, co
 	const bool act = lane < rb;
 	const ldsd *vc = l.TV + k1 * LDV + k1 + (act ? lane : 0);
 #pragma unroll
-	for (int j = 0; j < NR; ++j)
-		Urow[j] = vc[(j < rb ? j : 0) * LDV];
+	for (int b = 0; b < NR / 8; ++b) {
+		if (8 * b >= rb) {
 #pragma unroll
-	for (int j = 0; j < NR; ++j)
-		pin(Urow[j]);
+			for (int j = 8 * b; j < 8 * b + 8; ++j)
+				Urow[j] = 0.0;
+			continue;
+		}
 #pragma unroll
-	for (int j = 0; j < NR; ++j)
-		Urow[j] = sel(act && j > lane && j < rb, Urow[j]);
+		for (int j = 8 * b; j < 8 * b + 8; ++j)
+			Urow[j] = vc[(j < rb ? j : 0) * LDV];
+#pragma unroll
+		for (int j = 8 * b; j < 8 * b + 8; ++j)
+			pin(Urow[j]);
+#pragma unroll
+		for (int j = 8 * b; j < 8 * b + 8; ++j)
+			Urow[j] = sel(act && j > lane && j < rb, Urow[j]);
+	}
 }
 
 // L y = t  (inv = 1 / L(lane, lane), 0 for lanes >= rb); returns y_lane
@@ -593,7 +612,7 @@ __device__ inline double ls_solve_reg(int k1, int k2, int qB0, int qB1, int nunp
 	const bool act = lane < rb;
 	const int pl = l.pivlane[k1 + (act ? lane : 0)];
 	const double rp = sel(act, l.rhs[pl]);  // rhs by pivot position
-	const double inv = sel(act, 1.0 / l.rdiag[k1 + (act ? lane : 0)]);
+	const double inv = sel(act, fast_rcp(l.rdiag[k1 + (act ? lane : 0)]));
 	if (nunp == 0) {
 		double Lrow[NR];
 		load_Lrow(Lrow, k1, rb, l);
@@ -1261,7 +1280,7 @@ __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState 
 			} else {
 				// ---- 4t. T z = c1, y = Pi z (+ eps term: z <- z - eps (T'T)^-1 z) ----
 				const bool act = lane < nz;
-				double inv = 1.0 / l.rdiag[act ? lane : 0];
+				double inv = fast_rcp(l.rdiag[act ? lane : 0]);
 				inv = sel(act, inv);
 				double Urow[NR];
 				load_Urow(Urow, 0, nz, l);
@@ -1494,19 +1513,17 @@ __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState 
 				if (t > 0.0)
 					tb = t;
 			}
+			// derivative of the piecewise quadratic just right of this lane's breakpoint; the soft
+			// rows [P, Pn) are broadcast from their lanes (no LDS round trip per row)
 			double dmine = -1.0;
-			if (tb < 1e299) {
+			{
 				double acc = q0 + q1 * tb;
-				unsigned long long mk = softmask;
-				while (mk) {
-					int r = __ffsll((long long)mk) - 1;
-					mk &= mk - 1;
-					double cr = l.c[r];
-					double sv = l.s[r] + tb * cr;
-					if (sv > 0.0 && r != lane)
-						acc = fma(cr, sv, acc);
+				for (int r = P; r < Pn; ++r) {
+					const double cr = readlane_d(ci, r), sr = readlane_d(si, r);
+					const double sv = fma(tb, cr, sr);
+					acc = (sv > 0.0 && r != lane) ? fma(cr, sv, acc) : acc;
 				}
-				dmine = acc;
+				dmine = (tb < 1e299) ? acc : -1.0;
 			}
 			const double t_hi = wave_min((tb < 1e299 && dmine >= 0.0) ? tb : 1e300);
 			const double t_lo = wave_max((tb < t_hi) ? tb : 0.0);
