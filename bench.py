@@ -141,6 +141,18 @@ def main():
         value = total / elapsed
         kern_s = kern_ms * 1e-3
         achieved_gbs = ALG_BYTES_PER_SOLVE * args.batch / kern_s / 1e9 if kern_s > 0 else 0.0
+        # HBM bytes per launch of the dominant kernel from the committed PMC pass of this same
+        # command (tools_profile.sh; separate --pmc runs).  Only reported for the profiled
+        # workload; FETCH_SIZE is uncalibrated for 8-byte-per-lane loads on gfx950.
+        traffic, traffic_src = None, None
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")) as f:
+                tj = json.load(f)
+            if tj.get("batch") == args.batch and tj.get("semantics") == args.mode and tj.get("contact") == args.contact:
+                traffic = float(tj["fetch_bytes_per_launch"] + tj["write_bytes_per_launch"])
+                traffic_src = tj.get("source")
+        except (OSError, ValueError, KeyError):
+            pass
         res = {
             "metric": "fp64 HO-QP solves/sec (ANYmal-C, 4 contacts)",
             "value": value,
@@ -159,7 +171,8 @@ def main():
                        "batch_per_gpu": args.batch, "semantics": args.mode, "contact": args.contact,
                        "entry": "hoqp_solve_wbc_batched", "gather": bool(world > 1 and not args.no_gather)},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "kernel": "hoqp_solve_kernel", "kernel_ms": kern_ms, "launches_timed": kern_n,
                          "alg_bytes_per_solve": ALG_BYTES_PER_SOLVE,
                          "fp64_vector": {"achieved_tflops": ALG_FLOPS_PER_SOLVE * args.batch / kern_s / 1e12

@@ -167,3 +167,61 @@ def test_generic_tasks(solver_factory, oracle, mode, n, spec):
                 _close(o["level_res"][i, k], res_ref, f"level_res {k} inst {i}")
         if full_rank_end:
             _close(o["x"][i], r["x_levels"][L - 1], f"x inst {i}")
+
+
+def _lowrank(rng, B, m, n, r):
+    """m rows of rank r (every row a random combination of r base rows)."""
+    base = rng.normal(size=(B, r, n))
+    mix = rng.normal(size=(B, m, r))
+    return np.einsum("bmr,brn->bmn", mix, base)
+
+
+@pytest.mark.parametrize("mode", ["reference", "paper"])
+@pytest.mark.parametrize("case", ["wide_many_dependent", "tall_rank_deficient", "few_dependent", "n32"])
+def test_structured_tasks(solver_factory, oracle, mode, case):
+    """Rank-deficient and extreme-shape levels: the dependent-row paths of the least squares
+    (low-rank correction for <= 8 dependent rows, semi-normal equations beyond), the fallback of a
+    tall level that turns out rank deficient, and n = 32 (no spare lane in the projection)."""
+    import torch
+
+    rng = np.random.default_rng(99)
+    B = 32
+    if case == "wide_many_dependent":      # 16 rows of rank 4 in 20 unknowns: 12 dependent rows
+        n = 20
+        tasks = [{"A": _lowrank(rng, B, 16, n, 4), "b": rng.normal(size=(B, 16))},
+                 {"A": rng.normal(size=(B, 22, n)), "b": rng.normal(size=(B, 22))}]
+    elif case == "tall_rank_deficient":    # 14 rows of rank 3 in 10 unknowns
+        n = 10
+        tasks = [{"A": _lowrank(rng, B, 14, n, 3), "b": rng.normal(size=(B, 14))},
+                 {"A": rng.normal(size=(B, 12, n)), "b": rng.normal(size=(B, 12))}]
+    elif case == "few_dependent":          # 6 rows of rank 4, an inequality level, then everything pinned
+        n = 12
+        tasks = [{"A": _lowrank(rng, B, 6, n, 4), "b": rng.normal(size=(B, 6))},
+                 {"D": rng.normal(size=(B, 5, n)), "f": rng.normal(size=(B, 5)) + 0.5},
+                 {"A": rng.normal(size=(B, 14, n)), "b": rng.normal(size=(B, 14))}]
+    else:                                   # n = 32
+        n = 32
+        tasks = [{"A": rng.normal(size=(B, 8, n)), "b": rng.normal(size=(B, 8))},
+                 {"D": rng.normal(size=(B, 10, n)), "f": rng.normal(size=(B, 10)) + 0.5},
+                 {"A": rng.normal(size=(B, 32, n)), "b": rng.normal(size=(B, 32))}]
+    s = solver_factory(mode)
+    dtasks = [{k: torch.as_tensor(v).contiguous().cuda() for k, v in t.items()} for t in tasks]
+    out = s.solve_tasks(dtasks, n)
+    s.synchronize()
+    o = {k: v.cpu().numpy() for k, v in out.items()}
+    cfg = oracle.default_cfg(mode)
+    L = len(tasks)
+    assert np.all(o["status"] == 0), np.unique(o["status"])
+    for i in range(B):
+        r = oracle.solve_tasks([{k: v[i] for k, v in t.items()} for t in tasks], n, cfg)
+        assert r["rc"] == 0
+        voff = 0
+        for k, t in enumerate(tasks):
+            if "D" in t:
+                p = t["D"].shape[1]
+                _close(o["v"][i, voff:voff + p], r["v_levels"][k], f"{case}: v level {k} inst {i}")
+                voff += p
+            if "A" in t:
+                res_ref = np.linalg.norm(t["A"][i] @ r["x_levels"][k] - t["b"][i])
+                _close(o["level_res"][i, k], res_ref, f"{case}: level_res {k} inst {i}")
+        _close(o["x"][i], r["x_levels"][L - 1], f"{case}: x inst {i}")
