@@ -18,3 +18,10 @@ pmc sq2 SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_WAIT_IN
 pmc sqc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES
 cd $ROOT
 python3 tools_profile_summarize.py gpurun_out/rocprof gpurun_out/rocprof/summary
+# full bench line (with the CPU baseline) and the per-section cycle profile of the profiling build
+timeout -k 10 400 python3 bench.py > gpurun_out/rocprof/bench_full.json
+HOQP_DBG=1 HOQP_LIB=$PWD/quadruped_locomotion_amd/libhoqp_hip_prof.so timeout -k 10 200 python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 2> gpurun_out/rocprof/sections_reference.txt > /dev/null
+HOQP_DBG=1 HOQP_LIB=$PWD/quadruped_locomotion_amd/libhoqp_hip_prof.so timeout -k 10 200 python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 --mode paper 2> gpurun_out/rocprof/sections_paper.txt > /dev/null
+timeout -k 10 200 python3 bench.py --no-cpu-baseline --mode paper > gpurun_out/rocprof/bench_paper.json
+timeout -k 10 200 python3 bench.py --no-cpu-baseline --contact trot > gpurun_out/rocprof/bench_trot.json
+echo all done
