@@ -93,7 +93,7 @@ struct Lds {
 	ldsi *pivlane, *W, *xlane, *colpos, *vlist;
 };
 
-__device__ inline Lds lds_bind(const SolveArgs &a, HOQP_LDS char *base)
+__device__ __forceinline__ Lds lds_bind(const SolveArgs &a, HOQP_LDS char *base)
 {
 	const LdsOff o = lds_offsets(a);
 	Lds l;
@@ -339,7 +339,7 @@ __device__ __forceinline__ int panel_factor_t(double (&x)[NSP][NT], int (&pos)[N
 
 // slot count fixed at compile time inside the step loop (a per-slot scalar branch in every
 // step cost more than the slot's arithmetic); one dispatch per factorization
-__device__ inline int panel_factor(double (&x)[NSP][NT], int (&pos)[NSP], int nslot, int qlo, int qhi, int nr, int k0,
+__device__ __forceinline__ int panel_factor(double (&x)[NSP][NT], int (&pos)[NSP], int nslot, int qlo, int qhi, int nr, int k0,
 				   double rtol, const Lds &l, unsigned long long *dbgp = nullptr)
 {
 	if (nslot <= 1)
@@ -408,7 +408,7 @@ __device__ __forceinline__ void rows_apply_reflectors_t(ldsd *A0, int n0, ldsd *
 }
 
 // slot count fixed at compile time (see panel_factor)
-__device__ inline void rows_apply_reflectors(ldsd *A0, int n0, ldsd *A1, int n1, int ldr, int nr, int ka, int kb,
+__device__ __forceinline__ void rows_apply_reflectors(ldsd *A0, int n0, ldsd *A1, int n1, int ldr, int nr, int ka, int kb,
 					     const Lds &l)
 {
 	const int R = n0 + n1;
@@ -422,7 +422,7 @@ __device__ inline void rows_apply_reflectors(ldsd *A0, int n0, ldsd *A1, int n1,
 
 // out[r] = rows[r][0..nr) . vec[0..nr) for r < R (row r owned by quad r & 15, slot r >> 4)
 template <int NS>
-__device__ inline void rows_dot(const ldsd *A, int R, int ldr, int nr, const ldsd *vec, ldsd *out)
+__device__ __forceinline__ void rows_dot(const ldsd *A, int R, int ldr, int nr, const ldsd *vec, ldsd *out)
 {
 	const int lane = lane_id(), s = lane & 3, c = lane >> 2;
 	if (R <= 0)
@@ -458,7 +458,7 @@ __device__ inline void rows_dot(const ldsd *A, int R, int ldr, int nr, const lds
 }
 
 // One entry per lane.  forward: vec <- H_(kb-1) ... H_ka vec ; else vec <- H_ka ... H_(kb-1) vec.
-__device__ inline double hh_apply_vec(double vi, int nr, int ka, int kb, bool forward, const Lds &l)
+__device__ __forceinline__ double hh_apply_vec(double vi, int nr, int ka, int kb, bool forward, const Lds &l)
 {
 	const int lane = lane_id();
 	for (int t = 0; t < kb - ka; ++t) {
@@ -594,7 +594,7 @@ __device__ __forceinline__ double gauss_jordan8(double mval, double gval)
 // Unpivoted B columns (over-determined case) must have been dumped by the caller to
 // l.X[u*ld + i] with their lanes listed in l.xlane[0..nunp).
 // ---------------------------------------------------------------------------
-__device__ inline double ls_solve_reg(int k1, int k2, int qB0, int qB1, int nunp, double eps, int ld,
+__device__ __forceinline__ double ls_solve_reg(int k1, int k2, int qB0, int qB1, int nunp, double eps, int ld,
 				      double *res_norm2, const Lds &l)
 {
 	const int lane = lane_id();
@@ -847,7 +847,7 @@ __device__ __forceinline__ ProjLane proj_lane(int nz)
 	return p;
 }
 
-__device__ inline void project_task(const double *__restrict__ rows_g, const double *__restrict__ rhs_g, int rows,
+__device__ __forceinline__ void project_task(const double *__restrict__ rows_g, const double *__restrict__ rhs_g, int rows,
 				    int nstore, int n, int nz, int ld, const double (&zc)[NR], bool to_T, int P,
 				    const Lds &l)
 {
@@ -966,7 +966,7 @@ __device__ __forceinline__ int unp_index(bool unp, int &base)
 //   [ G_W' | B0' | G_V' ]  (w + m + |V| <= 64 columns, rows of V listed in l.vlist).
 // Returns p_i in lane i; *k1_out = rank of the working set (reflectors [0,k1) stay in TV).
 // ---------------------------------------------------------------------------
-__device__ inline double eqp_step(const SolveArgs &a, const Lds &l, LevelState &st, int nz, int rank, int m, int w,
+__device__ __forceinline__ double eqp_step(const SolveArgs &a, const Lds &l, LevelState &st, int nz, int rank, int m, int w,
 				  int nV, int *k1_out, bool *overflow)
 {
 	const int lane = lane_id(), s = lane & 3, c = lane >> 2;
@@ -1137,7 +1137,7 @@ __device__ __forceinline__ void level_update_t(const Lds &l, int n, int Pg, int 
 // ---------------------------------------------------------------------------
 // one priority level (HoQpProblem constructor pipeline, ho_qp_problem.cpp:11-25)
 // ---------------------------------------------------------------------------
-__device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState &st, int inst, int k, int m, int p)
+__device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, LevelState &st, int inst, int k, int m, int p)
 {
 	const int lane = lane_id(), s = lane & 3, c = lane >> 2;
 	const int n = uni(st.n), ld = a.ld;
@@ -1423,6 +1423,13 @@ __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState 
 		const bool isSoft = lane < Pn && ((softmask >> lane) & 1ull);
 		const double tolv = 1e-11 * (1.0 + fabs(gl));
 		bool done = false;
+		// After a full, unblocked step (t = 1) that leaves the set of violated soft rows unchanged
+		// the iterate IS the minimiser of the model the last equality-constrained step was
+		// computed for: the next step would be zero, so its factorization is skipped and the
+		// multipliers are read from the reflectors still in TV.
+		unsigned long long prev_vmask = 0ull;
+		bool prev_full = false;
+		int k1_keep = 0;
 		for (iters = 0; iters < a.max_iter && !done; ++iters) {
 			const double si = sel(lane < Pn, l.s[lane < Pn ? lane : 0]);
 			const double rj = sel(lane < mB, l.rho[lane < mB ? lane : 0]);
@@ -1431,14 +1438,23 @@ __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState 
 			const int nV = __popcll(vmask);
 			if (viol)
 				l.vlist[__popcll(vmask & ((1ull << lane) - 1ull))] = lane;
-			int k1 = 0;
-			bool overflow = false;
-			HOQP_STAMP(5);
-			const double pi = eqp_step(a, l, st, nz, rank, mB, w, nV, &k1, &overflow);
-			if (overflow) {
-				st.status |= HOQP_STATUS_WORKSPACE;
+			if (w + mB + nV == 0) {  // nothing to minimise, nothing active: y is optimal
+				done = true;
 				break;
 			}
+			int k1 = k1_keep;
+			bool overflow = false;
+			HOQP_STAMP(5);
+			double pi = 0.0;
+			if (!(prev_full && vmask == prev_vmask)) {
+				pi = eqp_step(a, l, st, nz, rank, mB, w, nV, &k1, &overflow);
+				if (overflow) {
+					st.status |= HOQP_STATUS_WORKSPACE;
+					break;
+				}
+				k1_keep = k1;
+			}
+			prev_full = false;
 			const double pn = wave_max(fabs(pi));
 			const double yn = wave_max(fabs(yi));
 			if (!(pn > 1e-10 * (1.0 + yn))) {
@@ -1543,6 +1559,8 @@ __device__ inline void solve_level(const SolveArgs &a, const Lds &l, LevelState 
 			else
 				t_star = (t_hi < 1e299) ? t_hi : t_lo;
 			const double t = fmin(t_star, t_hard);
+			prev_full = fabs(t - 1.0) <= 1e-9 && !(t_hard <= t_star && blk >= 0);
+			prev_vmask = vmask;
 			yi = fma(t, pi, yi);
 			wave_sync();
 			if (lane < Pn)
