@@ -1408,20 +1408,48 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 		if (lane < mB)
 			l.rho[lane] = -l.r0[lane];
 		wave_sync();
-		const unsigned long long softmask = (p >= 64) ? ~0ull : (((1ull << p) - 1ull) << P);
-		const unsigned long long hardmask = (P >= 64) ? ~0ull : ((1ull << P) - 1ull);
-		unsigned long long wmask = 0ull;
-		int w = 0;
+		const unsigned long long softmask_main = (p >= 64) ? ~0ull : (((1ull << p) - 1ull) << P);
+		const unsigned long long hardmask_main = (P >= 64) ? ~0ull : ((1ull << P) - 1ull);
+		const double gl = sel(lane < Pn, l.g[lane < Pn ? lane : 0]);
+		const double tolv = 1e-11 * (1.0 + fabs(gl));
+		// Phase 1 (only when a prior row is violated at y = 0, which reference semantics allow:
+		// levels without inequalities ignore the prior rows, ho_qp_problem.cpp:325-329): the same
+		// loop with the prior rows as the only, soft, rows finds a feasible y; the main phase
+		// then starts there.
+		bool need_p1;
 		{
+			int bad = 0;
+			if (lane < P)
+				bad = l.s[lane] > 1e-9 * (1.0 + fabs(l.g[lane]));
+			need_p1 = __ballot(bad) != 0ull;
+		}
+		const int mB_main = mB;
+		iters = 0;
+		for (int phase = need_p1 ? 0 : 1; phase < 2; ++phase) {
+		const bool p1 = phase == 0;
+		const unsigned long long softmask = p1 ? hardmask_main : softmask_main;
+		const unsigned long long hardmask = p1 ? 0ull : hardmask_main;
+		const int soft_lo = p1 ? 0 : P, soft_hi = p1 ? P : Pn;
+		mB = p1 ? 0 : mB_main;
+		if (!p1 && need_p1) {
+			// feasibility reached?  then rho = B y - r0 at the phase-1 point
 			int bad = 0;
 			if (lane < P)
 				bad = l.s[lane] > 1e-9 * (1.0 + fabs(l.g[lane]));
 			if (__ballot(bad))
 				st.status |= HOQP_STATUS_INFEASIBLE_START;
+			wave_sync();
+			l.tmp[lane] = (lane < nz) ? yi : 0.0;
+			wave_sync();
+			rows_dot<2>(l.BL, mB, ld, rank, l.tmp, l.a0);
+			wave_sync();
+			if (lane < mB)
+				l.rho[lane] = l.a0[lane] - l.r0[lane];
+			wave_sync();
 		}
-		const double gl = sel(lane < Pn, l.g[lane < Pn ? lane : 0]);
+		unsigned long long wmask = 0ull;
+		int w = 0;
 		const bool isSoft = lane < Pn && ((softmask >> lane) & 1ull);
-		const double tolv = 1e-11 * (1.0 + fabs(gl));
 		bool done = false;
 		// After a full, unblocked step (t = 1) that leaves the set of violated soft rows unchanged
 		// the iterate IS the minimiser of the model the last equality-constrained step was
@@ -1430,7 +1458,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 		unsigned long long prev_vmask = 0ull;
 		bool prev_full = false;
 		int k1_keep = 0;
-		for (iters = 0; iters < a.max_iter && !done; ++iters) {
+		for (; iters < a.max_iter && !done; ++iters) {
 			const double si = sel(lane < Pn, l.s[lane < Pn ? lane : 0]);
 			const double rj = sel(lane < mB, l.rho[lane < mB ? lane : 0]);
 			const bool viol = isSoft && si > tolv;
@@ -1534,7 +1562,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 			double dmine = -1.0;
 			{
 				double acc = q0 + q1 * tb;
-				for (int r = P; r < Pn; ++r) {
+				for (int r = soft_lo; r < soft_hi; ++r) {
 					const double cr = readlane_d(ci, r), sr = readlane_d(si, r);
 					const double sv = fma(tb, cr, sr);
 					acc = (sv > 0.0 && r != lane) ? fma(cr, sv, acc) : acc;
@@ -1581,8 +1609,13 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 			wave_sync();
 			HOQP_STAMP(13);
 		}
-		if (!done)
+		if (!done) {
 			st.status |= HOQP_STATUS_MAX_ITER;
+			break;
+		}
+		}  // phase
+		mB = mB_main;
+
 		{
 			double rj = sel(lane < mB, l.rho[lane < mB ? lane : 0]);
 			level_res2 = wave_sum(rj * rj) + res_const;
