@@ -21,7 +21,8 @@ constexpr int NT = NR / 4; // entries of one vector held by one lane
 constexpr int NSP = 4;	  // panel slots: 64 columns  (working set + LS rows + violated rows)
 constexpr int NSR = 6;	  // row slots: 96 rows >= HOQP_MAX_VARS + HOQP_MAX_INEQ_ROWS
 constexpr int LDV = 34;	  // leading dimension of the reflector store
-constexpr int SROW = 32;  // row stride of the task staging buffer
+constexpr int SROW = 36;  // row stride of the task staging buffer (16-byte aligned rows; 36 keeps the
+			  // 16-rows-by-4-columns MFMA operand read at a 2-way bank conflict, 32 would be 16-way)
 constexpr int XROWS = 16; // dumped unpivoted columns (rank-deficient least squares); aliases S
 constexpr int CHUNK = 16; // task rows staged per pass
 
@@ -922,6 +923,131 @@ __device__ __forceinline__ void project_task(const double *__restrict__ rows_g, 
 	wave_sync();
 }
 
+// ---------------------------------------------------------------------------
+// Task projection on the matrix cores (n_z <= 31).  A chunk of 16 staged task rows is one
+// 16 x K operand tile of v_mfma_f64_16x16x4_f64; [Z | x] (n x (n_z + 1)) is the other operand,
+// kept in registers for the whole level:  bm[kb][cb] = B[k = 4 kb + lane/16][j = 16 cb + lane%16]
+// with B[k][j] = Z[k][j] (j < n_z), x[k] (j == n_z), 0 otherwise / for k >= n.
+// Operand layout of the instruction on gfx950 (probed, tools_mfma/mfma_layout.hip):
+//   A[i = lane%16][k = lane/16],  B[k = lane/16][j = lane%16],  D[i = lane/16 + 4 r][j = lane%16].
+// Outputs as in project_task: (A Z) rows -> TV / G, right-hand side minus (a_r x) -> rhs / g.
+// ---------------------------------------------------------------------------
+typedef double d4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void load_bm(double (&bm)[NR / 4][2], int n, int nz, int ld, const Lds &l)
+{
+	const int lane = lane_id(), j16 = lane & 15, q4 = lane >> 4;
+#pragma unroll
+	for (int kb = 0; kb < NR / 4; ++kb) {
+		const int k = 4 * kb + q4;
+		const int kc = (k < n) ? k : 0;
+#pragma unroll
+		for (int cb = 0; cb < 2; ++cb) {
+			const int j = 16 * cb + j16;
+			const ldsd *src = (j < nz) ? l.Z + kc * ld + j : l.x + kc;
+			bm[kb][cb] = *src;
+		}
+	}
+#pragma unroll
+	for (int kb = 0; kb < NR / 4; ++kb) {
+		pin(bm[kb][0]);
+		pin(bm[kb][1]);
+	}
+#pragma unroll
+	for (int kb = 0; kb < NR / 4; ++kb) {
+		const int k = 4 * kb + q4;
+#pragma unroll
+		for (int cb = 0; cb < 2; ++cb) {
+			const int j = 16 * cb + j16;
+			bm[kb][cb] = sel(k < n && j <= nz, bm[kb][cb]);
+		}
+	}
+}
+
+__device__ __forceinline__ void project_task_mfma(const double *__restrict__ rows_g, const double *__restrict__ rhs_g,
+						  int rows, int nstore, int nz, int ld, const double (&bm)[NR / 4][2],
+						  bool to_T, int P, const Lds &l)
+{
+	const int lane = lane_id();
+	const int c = lane & 31, h = lane >> 5;
+	const int j16 = lane & 15, q4 = lane >> 4;
+	const int cc = (c < nstore) ? c : 0;
+	const bool two = nz + 1 > 16;  // second block of 16 output columns needed
+	double pre[CHUNK / 2];
+	double rv_next;
+	auto fetch = [&](int r0) {
+		const int nr = min(CHUNK, rows - r0);
+#pragma unroll
+		for (int t = 0; t < CHUNK / 2; ++t) {
+			const int r = 2 * t + h;
+			pre[t] = rows_g[(size_t)(r0 + (r < nr ? r : 0)) * nstore + cc];
+		}
+		rv_next = rhs_g[r0 + (lane < nr ? lane : 0)];
+	};
+	fetch(0);
+	for (int r0 = 0; r0 < rows; r0 += CHUNK) {
+		const int nr = min(CHUNK, rows - r0);
+		wave_sync();  // readers of the previous chunk are done with S and tmp
+#pragma unroll
+		for (int t = 0; t < CHUNK / 2; ++t)
+			l.S[(2 * t + h) * SROW + c] = pre[t];
+		l.tmp[lane] = rv_next;
+		wave_sync();
+		if (r0 + CHUNK < rows)
+			fetch(r0 + CHUNK);
+		double av[NR / 4], rvr[4];
+#pragma unroll
+		for (int kb = 0; kb < NR / 4; ++kb)
+			av[kb] = l.S[j16 * SROW + 4 * kb + q4];
+#pragma unroll
+		for (int r = 0; r < 4; ++r)
+			rvr[r] = l.tmp[q4 + 4 * r];
+#pragma unroll
+		for (int kb = 0; kb < NR / 4; ++kb)
+			pin(av[kb]);
+#pragma unroll
+		for (int r = 0; r < 4; ++r)
+			pin(rvr[r]);
+		d4v acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+		if (two) {
+#pragma unroll
+			for (int kb = 0; kb < NR / 4; ++kb) {
+				acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kb], bm[kb][0], acc0, 0, 0, 0);
+				acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kb], bm[kb][1], acc1, 0, 0, 0);
+			}
+		} else {
+#pragma unroll
+			for (int kb = 0; kb < NR / 4; ++kb)
+				acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kb], bm[kb][0], acc0, 0, 0, 0);
+		}
+		// D[i = q4 + 4 r][j = j16 (+16)]: one store per held entry (projected entry, right-hand
+		// side, or the lane's sink)
+#pragma unroll
+		for (int cb = 0; cb < 2; ++cb) {
+			if (cb == 1 && !two)
+				continue;
+			const int j = 16 * cb + j16;
+			const bool isZ = j < nz, isX = j == nz;
+#pragma unroll
+			for (int r = 0; r < 4; ++r) {
+				const int i = q4 + 4 * r;
+				const bool rok = i < nr;
+				const double v = cb ? acc1[r] : acc0[r];
+				ldsd *dst = l.dump + lane;
+				if (to_T) {
+					dst = (isZ && rok) ? l.TV + (r0 + i) * ld + j : dst;
+					dst = (isX && rok) ? l.rhs + (r0 + i) : dst;
+				} else {
+					dst = (isZ && rok) ? l.G + (P + r0 + i) * ld + j : dst;
+					dst = (isX && rok) ? l.g + (P + r0 + i) : dst;
+				}
+				*dst = isX ? rvr[r] - v : v;
+			}
+		}
+	}
+	wave_sync();
+}
+
 #ifdef HOQP_PROFILE
 #define HOQP_STAMP(slot)                                                              \
 	do {                                                                          \
@@ -1164,7 +1290,16 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 	// ---- 1. project the task into the current null space (ConstructH/C/D/FVector,
 	//         ho_qp_problem.cpp:180-285, in factored form) ----
 	auto project = [&](bool doA, bool doD) {
-		{
+		if (nz < 32) {  // matrix-core path
+			double bm[NR / 4][2];
+			load_bm(bm, n, nz, ld, l);
+			if (m > 0 && doA)
+				project_task_mfma(a.A[k] + (size_t)inst * a.m[k] * nstore, a.b[k] + (size_t)inst * a.m[k], m,
+						  nstore, nz, ld, bm, true, 0, l);
+			if (p > 0 && doD)
+				project_task_mfma(a.D[k] + (size_t)inst * a.p[k] * nstore, a.f[k] + (size_t)inst * a.p[k], p,
+						  nstore, nz, ld, bm, false, P, l);
+		} else {
 			double zc[NR];
 			const ProjLane pl = proj_lane(nz);
 			const ldsd *src = pl.isZ ? l.Z + pl.j : l.x;
