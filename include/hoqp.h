@@ -158,6 +158,21 @@ int hoqp_solve_wbc_batched(hoqp_handle *h, const hoqp_wbc_inputs *in, const hoqp
 int hoqp_solve_tasks_host(hoqp_handle *h, const hoqp_task_batch *tasks, const hoqp_result_batch *out);
 int hoqp_solve_wbc_host(hoqp_handle *h, const hoqp_wbc_inputs *in, const hoqp_wbc_outputs *out);
 
+/* Post-solve step of the whole-body controller, batched and device resident:
+ * the two forward-Euler integrations that turn the joint acceleration command into velocity and
+ * position commands (WholeBodyController::SetJointCmdFromIntegrators,
+ * whole_body_controller.cpp:148-155; Integrator::Integrate, integrator.cpp:31-36) followed by the
+ * joint PD + feed-forward torque (JointController::CalcJointTorques, joint_controller.cpp:103-110):
+ *     qd_cmd += dt * qdd;   q_cmd += dt * qd_cmd;                 (in place, the integrator state)
+ *     tau_cmd = kp * (q_cmd - q_j) + kd * (qd_cmd - qd_j) + tau_ff
+ * All arrays are [batch][12] doubles on the device.  `qdd` and `tau_ff` are the outputs `qdd` and
+ * `tau` of hoqp_solve_wbc_batched; q_j / qd_j are the measured joint positions / velocities
+ * (q[7:19], u[6:18] of the WBC inputs).  The reference takes dt from ros::Time (wall clock);
+ * here it is an argument.  tau_cmd may be NULL (integration only).  Asynchronous on `stream`. */
+int hoqp_wbc_poststep_batched(hoqp_handle *h, int batch, double dt, double kp, double kd, const double *qdd,
+			      const double *tau_ff, const double *q_j, const double *qd_j, double *q_cmd,
+			      double *qd_cmd, double *tau_cmd, void *stream);
+
 /* Blocks until `stream` has drained; returns <0 if a kernel faulted. */
 int hoqp_synchronize(hoqp_handle *h, void *stream);
 

@@ -1080,3 +1080,20 @@ int hoqp_oracle_wbc_solve_batch(const hoqp_oracle_cfg *cfg, const hoqp_oracle_wb
 		rc |= hoqp_oracle_wbc_solve(cfg, prm, s + i, out + i);
 	return rc;
 }
+
+/* ---------------------------------------------------------------------------
+ * Post-solve step.  q_j_ddot_cmd_integrator_.Integrate(q_j_ddot_cmd_) makes the
+ * velocity command, q_j_dot_cmd_integrator_.Integrate(q_j_dot_cmd_) the position command
+ * (whole_body_controller.cpp:148-155; integral_ += dt_ * vec, integrator.cpp:31-36); the joint
+ * controller then forms tau = kp (q* - q) + kd (qd* - qd) + tau_ff (joint_controller.cpp:103-110).
+ * --------------------------------------------------------------------------- */
+void hoqp_oracle_wbc_poststep(int N, double dt, double kp, double kd, const double *qdd, const double *tau_ff,
+			      const double *q_j, const double *qd_j, double *q_cmd, double *qd_cmd, double *tau_cmd)
+{
+	for (long i = 0; i < (long)N * 12; ++i) {
+		qd_cmd[i] += dt * qdd[i];
+		q_cmd[i] += dt * qd_cmd[i];
+		if (tau_cmd)
+			tau_cmd[i] = kp * (q_cmd[i] - q_j[i]) + kd * (qd_cmd[i] - qd_j[i]) + tau_ff[i];
+	}
+}

@@ -78,4 +78,11 @@ int hoqp_oracle_wbc_solve_batch(const hoqp_oracle_cfg *cfg, const hoqp_oracle_wb
 #ifdef __cplusplus
 }
 #endif
+/* Post-solve step: Integrator::Integrate twice (integrator.cpp:31-36, called by
+ * WholeBodyController::SetJointCmdFromIntegrators, whole_body_controller.cpp:148-155) and
+ * JointController::CalcJointTorques (joint_controller.cpp:103-110); arrays [N][12]; q_cmd and
+ * qd_cmd are updated in place; dt is an argument (the reference reads the wall clock). */
+void hoqp_oracle_wbc_poststep(int N, double dt, double kp, double kd, const double *qdd, const double *tau_ff,
+			      const double *q_j, const double *qd_j, double *q_cmd, double *qd_cmd, double *tau_cmd);
+
 #endif

@@ -214,3 +214,15 @@ def wbc_solve_batch(inp, cfg=None, prm=None, threads=1):
     assert dt.itemsize == C.sizeof(WbcResult), (dt.itemsize, C.sizeof(WbcResult))
     out = np.frombuffer(res, dtype=dt).copy()
     return out, rc
+
+
+def wbc_poststep(dt, kp, kd, qdd, tau_ff, q_j, qd_j, q_cmd, qd_cmd):
+    """Post-solve step (N2): returns (q_cmd, qd_cmd, tau_cmd) as new arrays; inputs [N, 12]."""
+    N = qdd.shape[0]
+    arrs = [np.ascontiguousarray(a, dtype=np.float64).copy() for a in (qdd, tau_ff, q_j, qd_j, q_cmd, qd_cmd)]
+    tau = np.zeros((N, 12))
+    f = lib().hoqp_oracle_wbc_poststep
+    f.restype = None
+    f.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double] + [C.POINTER(C.c_double)] * 7
+    f(N, dt, kp, kd, *[_dp(a) for a in arrs], _dp(tau))
+    return arrs[4], arrs[5], tau

@@ -221,6 +221,25 @@ __global__ void wbc_finalize_kernel(hoqp_wbc_inputs in, const double *x, double 
 	}
 }
 
+// Post-solve step: Integrator::Integrate twice (integrator.cpp:31-36, called from
+// whole_body_controller.cpp:148-155), then JointController::CalcJointTorques
+// (joint_controller.cpp:103-110).  One thread per joint; pure streaming (HBM bound).
+__global__ void wbc_poststep_kernel(int total, double dt, double kp, double kd, const double *__restrict__ qdd,
+				    const double *__restrict__ tau_ff, const double *__restrict__ q_j,
+				    const double *__restrict__ qd_j, double *__restrict__ q_cmd,
+				    double *__restrict__ qd_cmd, double *__restrict__ tau_cmd)
+{
+	const int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= total)
+		return;
+	const double qd = qd_cmd[t] + dt * qdd[t];
+	const double q = q_cmd[t] + dt * qd;
+	qd_cmd[t] = qd;
+	q_cmd[t] = q;
+	if (tau_cmd)
+		tau_cmd[t] = kp * (q - q_j[t]) + kd * (qd - qd_j[t]) + tau_ff[t];
+}
+
 // ---------------------------------------------------------------------------
 // device self-test of the cross-lane primitives
 // ---------------------------------------------------------------------------
@@ -632,6 +651,30 @@ extern "C" int hoqp_solve_wbc_batched(hoqp_handle *h, const hoqp_wbc_inputs *in,
 				   out->tau);
 		HIP_OK(h, hipGetLastError());
 	}
+	return 0;
+}
+
+extern "C" int hoqp_wbc_poststep_batched(hoqp_handle *h, int batch, double dt, double kp, double kd, const double *qdd,
+					 const double *tau_ff, const double *q_j, const double *qd_j, double *q_cmd,
+					 double *qd_cmd, double *tau_cmd, void *stream)
+{
+	if (!h)
+		return -1;
+	if (batch < 0)
+		return fail(h, -1, "negative batch");
+	if (!qdd || !q_cmd || !qd_cmd)
+		return fail(h, -1, "hoqp_wbc_poststep_batched: qdd, q_cmd and qd_cmd are required");
+	if (tau_cmd && (!tau_ff || !q_j || !qd_j))
+		return fail(h, -1, "hoqp_wbc_poststep_batched: tau_cmd needs tau_ff, q_j and qd_j");
+	if (batch == 0)
+		return 0;
+	HIP_OK(h, hipSetDevice(h->cfg.device));
+	const long long total = (long long)batch * kNJ;
+	if (total > 0x7fffffffLL)
+		return fail(h, -1, "batch too large");
+	hipLaunchKernelGGL(wbc_poststep_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+			   (int)total, dt, kp, kd, qdd, tau_ff, q_j, qd_j, q_cmd, qd_cmd, tau_cmd);
+	HIP_OK(h, hipGetLastError());
 	return 0;
 }
 

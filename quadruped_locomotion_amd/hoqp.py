@@ -33,7 +33,7 @@ STATUS_NONFINITE = 0x08
 EXPORTS = (
     "hoqp_default_config", "hoqp_create", "hoqp_destroy", "hoqp_last_error_string",
     "hoqp_solve_tasks_batched", "hoqp_solve_wbc_batched", "hoqp_solve_tasks_host", "hoqp_solve_wbc_host",
-    "hoqp_synchronize",
+    "hoqp_wbc_poststep_batched", "hoqp_synchronize",
     "hoqp_kernel_time_ms", "hoqp_selftest", "hoqp_lds_bytes",
 )
 
@@ -102,6 +102,7 @@ def load_library():
         lib.hoqp_solve_tasks_batched.argtypes = [C.c_void_p, C.POINTER(TaskBatch), C.POINTER(ResultBatch), C.c_void_p]
         lib.hoqp_solve_wbc_batched.argtypes = [C.c_void_p, C.POINTER(WbcInputs), C.POINTER(WbcOutputs), C.c_void_p]
         lib.hoqp_synchronize.argtypes = [C.c_void_p, C.c_void_p]
+        lib.hoqp_wbc_poststep_batched.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double] + [C.c_void_p] * 8
         lib.hoqp_kernel_time_ms.argtypes = [C.c_void_p, C.c_int, _dp, _ip]
         lib.hoqp_selftest.argtypes = [C.c_void_p]
         lib.hoqp_lds_bytes.argtypes = [C.c_int, C.c_int, _ip, _ip]
@@ -267,6 +268,23 @@ class HoQpSolver:
         """dict of numpy arrays (anymal_model.make_wbc_inputs) -> dict of device tensors."""
         t = self.torch
         return {k: t.as_tensor(v).contiguous().to(self.device) for k, v in inp.items()}
+
+    def wbc_poststep(self, dt, kp, kd, qdd, tau_ff, q_j, qd_j, q_cmd, qd_cmd, tau_cmd=None):
+        """In-place integrator update of (q_cmd, qd_cmd) and the PD + feed-forward torque
+        (hoqp_wbc_poststep_batched); all arguments are [batch, 12] float64 CUDA tensors."""
+        t = self.torch
+        B = qdd.shape[0]
+        ptrs = []
+        for name, arr in (("qdd", qdd), ("tau_ff", tau_ff), ("q_j", q_j), ("qd_j", qd_j), ("q_cmd", q_cmd),
+                          ("qd_cmd", qd_cmd), ("tau_cmd", tau_cmd)):
+            if arr is None:
+                ptrs.append(None)
+                continue
+            assert arr.dtype == t.float64 and arr.is_contiguous() and arr.is_cuda and tuple(arr.shape) == (B, 12), name
+            ptrs.append(C.c_void_p(arr.data_ptr()))
+        self._check(self.lib.hoqp_wbc_poststep_batched(self.h, B, C.c_double(dt), C.c_double(kp), C.c_double(kd),
+                                                       *ptrs, self._stream()), "hoqp_wbc_poststep_batched")
+        return tau_cmd
 
     def solve_wbc(self, dinp, out=None):
         t = self.torch

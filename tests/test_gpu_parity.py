@@ -227,3 +227,30 @@ def test_structured_tasks(solver_factory, oracle, mode, case):
                 res_ref = np.linalg.norm(t["A"][i] @ r["x_levels"][k] - t["b"][i])
                 _close(o["level_res"][i, k], res_ref, f"{case}: level_res {k} inst {i}")
         _close(o["x"][i], r["x_levels"][L - 1], f"{case}: x inst {i}")
+
+
+def test_wbc_poststep(solver_factory, oracle):
+    """N2 (post-solve step): integrators + joint PD torque against the oracle; the only rounding
+    freedom is fused multiply-add contraction, hence 1e-13 relative."""
+    import torch
+
+    rng = np.random.default_rng(5)
+    B = 1000
+    a = {k: rng.normal(size=(B, 12)) for k in ("qdd", "tau_ff", "q_j", "qd_j", "q_cmd", "qd_cmd")}
+    s = solver_factory("reference")
+    d = {k: torch.as_tensor(v).contiguous().cuda() for k, v in a.items()}
+    tau = torch.empty((B, 12), dtype=torch.float64, device="cuda")
+    q_ref, qd_ref, tau_ref = a["q_cmd"], a["qd_cmd"], None
+    for _ in range(3):  # three control cycles: the integrator state carries over
+        s.wbc_poststep(2.5e-3, 50.0, 1.5, d["qdd"], d["tau_ff"], d["q_j"], d["qd_j"], d["q_cmd"], d["qd_cmd"], tau)
+        q_ref, qd_ref, tau_ref = oracle.wbc_poststep(2.5e-3, 50.0, 1.5, a["qdd"], a["tau_ff"], a["q_j"], a["qd_j"],
+                                                     q_ref, qd_ref)
+    s.synchronize()
+    for got, ref in ((d["q_cmd"], q_ref), (d["qd_cmd"], qd_ref), (tau, tau_ref)):
+        err = np.abs(got.cpu().numpy() - ref) / np.maximum(1.0, np.abs(ref))
+        assert err.max() <= 1e-13, err.max()
+    # integration only (no torque output)
+    s.wbc_poststep(2.5e-3, 0.0, 0.0, d["qdd"], None, None, None, d["q_cmd"], d["qd_cmd"], None)
+    s.synchronize()
+    q4, qd4, _ = oracle.wbc_poststep(2.5e-3, 0.0, 0.0, a["qdd"], a["tau_ff"], a["q_j"], a["qd_j"], q_ref, qd_ref)
+    assert np.abs(d["q_cmd"].cpu().numpy() - q4).max() <= 1e-13

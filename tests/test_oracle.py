@@ -256,3 +256,13 @@ def test_golden_fixtures(oracle):
             assert np.all(np.abs(out[key] - ref) <= 1e-9 * np.maximum(1.0, np.abs(ref))), (name, key)
         assert np.array_equal(out["nz_levels"], g[f"{name}/out/nz_levels"])
         assert np.array_equal(out["flags"], g[f"{name}/out/flags"])
+
+
+def test_poststep_known_answer(oracle):
+    """N2: two Euler integrations then PD + feed-forward (whole_body_controller.cpp:148-155,
+    joint_controller.cpp:103-110) on hand-computed numbers."""
+    one = np.ones((1, 12))
+    q, qd, tau = oracle.wbc_poststep(0.5, 10.0, 2.0, 4.0 * one, 1.0 * one, 0.25 * one, 0.5 * one, 1.0 * one, 3.0 * one)
+    assert np.array_equal(qd, 5.0 * one)                 # 3 + 0.5 * 4
+    assert np.array_equal(q, 3.5 * one)                  # 1 + 0.5 * 5
+    assert np.array_equal(tau, (10 * 3.25 + 2 * 4.5 + 1) * one)
