@@ -127,7 +127,8 @@ def main():
     solver.timing(False)
 
     # p50/p99 batch latency (submit -> results visible), measured outside the timed region
-    for _ in range(min(args.steps, 300)):
+    # >= 1000 batches for the percentiles on a default run (fewer on short runs)
+    for _ in range(1000 if args.steps >= 200 else args.steps):
         torch.cuda.synchronize()
         a = time.perf_counter()
         step()
