@@ -158,6 +158,37 @@ int hoqp_solve_wbc_batched(hoqp_handle *h, const hoqp_wbc_inputs *in, const hoqp
 int hoqp_solve_tasks_host(hoqp_handle *h, const hoqp_task_batch *tasks, const hoqp_result_batch *out);
 int hoqp_solve_wbc_host(hoqp_handle *h, const hoqp_wbc_inputs *in, const hoqp_wbc_outputs *out);
 
+/*
+ * Dynamics-terms producer: what HoQpController::UpdateModelDynamics
+ * (ho_qp_controller.cpp:89-114) pulls from the reference's Dynamics object -- GetMassMatrix,
+ * GetBiasVector, GetStackedContactJacobianInW, GetStackedContactAccInW, foot positions,
+ * GetBaseSpatialJacobian (dynamics.cpp:75-124, 130-152, 179-228) -- batched on the device for a
+ * quadruped with 3 joints per leg (HAA about body x, HFE and KFE about y).  The reference gets
+ * these from Drake's MultibodyPlant on Drake's ANYmal-C URDF; neither exists here, so the model
+ * parameters are this library's own (defaults: an approximate 50 kg ANYmal-C, documented in
+ * quadruped_locomotion_amd/anymal_model.py) and parity of the MODEL is unpinned.
+ * Offsets and centres of mass are given for the LF leg; x is mirrored for hind legs (HAA offset
+ * only), y for right legs.  Inertias are principal moments in the body frame.
+ */
+typedef struct {
+	double base_mass, hip_mass, thigh_mass, shank_mass;
+	double base_inertia[3], hip_inertia[3], thigh_inertia[3], shank_inertia[3];
+	double haa_off[3], hfe_off[3], kfe_off[3], foot_off[3];
+	double hip_com[3], thigh_com[3], shank_com[3];
+	double gravity;
+} hoqp_quadruped_model;
+
+void hoqp_default_quadruped_model(hoqp_quadruped_model *model);
+
+/* q [batch][19] = quat wxyz, base position, joints; u [batch][18] = omega_W, v_W, joint rates
+ * (anymal_plugin.cpp:266-290).  Outputs in the layout of hoqp_wbc_inputs: M [batch][18][18],
+ * hvec [batch][18] (gravity included iff include_gravity; the reference's CalcBiasTerm has none,
+ * dynamics.cpp:82-87), Jfoot [batch][4][3][18], Jdotu [batch][4][3], footpos [batch][4][3],
+ * Jb [batch][6][18] (may be NULL).  model == NULL: defaults.  Asynchronous on `stream`. */
+int hoqp_wbc_dynamics_batched(hoqp_handle *h, const hoqp_quadruped_model *model, int batch, const double *q,
+			      const double *u, int include_gravity, double *M, double *hvec, double *Jfoot,
+			      double *Jdotu, double *footpos, double *Jb, void *stream);
+
 /* Post-solve step of the whole-body controller, batched and device resident:
  * the two forward-Euler integrations that turn the joint acceleration command into velocity and
  * position commands (WholeBodyController::SetJointCmdFromIntegrators,

@@ -1,0 +1,256 @@
+// wbc_dynamics.hpp -- batched dynamics-terms producer for a 12-joint quadruped.
+//
+// Produces exactly what HoQpController::UpdateModelDynamics pulls from the reference's Dynamics
+// object (ho_qp_controller.cpp:89-114; dynamics.cpp:75-124, 130-152, 179-228): mass matrix M,
+// bias vector h, translational foot Jacobians, J_dot*u of the feet, foot positions and the base
+// spatial Jacobian, in the layout of hoqp_wbc_inputs.  The reference gets them from Drake's
+// MultibodyPlant on Drake's ANYmal-C URDF; neither is available, so the model is this build's own
+// (parameters in hoqp_quadruped_model, defaults = quadruped_locomotion_amd/anymal_model.py) and
+// parity for the MODEL is unpinned; the kernel is checked against that numpy model.
+//
+// Conventions (anymal_plugin.cpp:266-290, anymal_constants.hpp:28-52):
+//   q = [quat wxyz, base position, 12 joints], u = [omega_W, v_W, 12 joint rates],
+//   joint j = kind*4 + leg (kind HAA/HFE/KFE, leg LF/RF/LH/RH);  M u_dot + h = S'tau + J_c'lambda.
+//
+// One wavefront per state.  Phase 1: lane b < 13 is one rigid body (base, then hip/thigh/shank of
+// each leg), lanes 13..16 the four feet; each walks its leg's chain and leaves the body's
+// Jacobians, world inertia and bias wrench in LDS.  Phase 2: the 324 entries of
+// M = sum_b m Jv'Jv + Jw' I_w Jw are spread over the lanes.  FLOP-light, latency-bound, 4 KB out.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/hoqp.h"
+#include "hoqp_device.hpp"
+
+namespace hoqp {
+
+namespace dyn {
+constexpr int NB = 13;		// rigid bodies
+constexpr int NU_ = 18;
+constexpr int JV = 0, JW = 54, IJ = 108, IW = 162, WF = 171, WT = 174, MS = 177, BSTR = 178;
+
+struct V3 {
+	double x, y, z;
+};
+__device__ __forceinline__ V3 v3(double x, double y, double z) { return {x, y, z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator*(V3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b)
+{
+	return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+struct M3 {  // columns
+	V3 c0, c1, c2;
+};
+__device__ __forceinline__ V3 mul(const M3 &R, V3 v) { return R.c0 * v.x + R.c1 * v.y + R.c2 * v.z; }
+__device__ __forceinline__ M3 mul(const M3 &A, const M3 &B) { return {mul(A, B.c0), mul(A, B.c1), mul(A, B.c2)}; }
+__device__ __forceinline__ M3 rot_x(double a)
+{
+	const double c = cos(a), s = sin(a);
+	return {v3(1, 0, 0), v3(0, c, s), v3(0, -s, c)};
+}
+__device__ __forceinline__ M3 rot_y(double a)
+{
+	const double c = cos(a), s = sin(a);
+	return {v3(c, 0, -s), v3(0, 1, 0), v3(s, 0, c)};
+}
+__device__ __forceinline__ V3 ld3(const double *p) { return {p[0], p[1], p[2]}; }
+// point acceleration with u_dot = 0: origin acceleration + alpha x d + w x (w x d)
+__device__ __forceinline__ V3 pt_acc(V3 acc_o, V3 al, V3 w, V3 d) { return acc_o + cross(al, d) + cross(w, cross(w, d)); }
+}  // namespace dyn
+
+__global__ void __launch_bounds__(kWave) wbc_dynamics_kernel(hoqp_quadruped_model md, int batch, int include_gravity,
+							     const double *__restrict__ qg, const double *__restrict__ ug,
+							     double *__restrict__ Mg, double *__restrict__ hg,
+							     double *__restrict__ Jfg, double *__restrict__ Jdug,
+							     double *__restrict__ fpg, double *__restrict__ Jbg)
+{
+	using namespace dyn;
+	__shared__ double sm[NB * BSTR];
+	const int lane = lane_id();
+	const int inst = blockIdx.x;
+	if (inst >= batch)
+		return;
+	const double *q = qg + (size_t)inst * 19;
+	const double *u = ug + (size_t)inst * 18;
+	for (int i = lane; i < NB * BSTR; i += kWave)
+		sm[i] = 0.0;
+	__syncthreads();
+
+	// ---- phase 1: one body (or foot) per lane ----
+	const bool isBody = lane < NB, isFoot = lane >= NB && lane < NB + 4;
+	const int leg = isFoot ? lane - NB : (lane > 0 && isBody ? (lane - 1) / 3 : 0);
+	const int link = (lane > 0 && isBody) ? (lane - 1) % 3 : 3;  // 0 hip, 1 thigh, 2 shank, 3 foot/base
+	if (isBody || isFoot) {
+		// base pose and twist
+		double qw = q[0], qx = q[1], qy = q[2], qz = q[3];
+		const double qn = 1.0 / sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
+		qw *= qn, qx *= qn, qy *= qn, qz *= qn;
+		const M3 Rb = {v3(1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy + qz * qw), 2 * (qx * qz - qy * qw)),
+			       v3(2 * (qx * qy - qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz + qx * qw)),
+			       v3(2 * (qx * qz + qy * qw), 2 * (qy * qz - qx * qw), 1 - 2 * (qx * qx + qy * qy))};
+		const V3 pb = ld3(q + 4), w0 = ld3(u), zero = v3(0, 0, 0);
+		const double sx = (leg < 2) ? 1.0 : -1.0, sy = (leg & 1) ? -1.0 : 1.0;
+		const double q1 = q[7 + leg], q2 = q[7 + 4 + leg], q3 = q[7 + 8 + leg];
+		const double d1 = u[6 + leg], d2 = u[6 + 4 + leg], d3 = u[6 + 8 + leg];
+		// kinematics of the leg (world frame)
+		const V3 o1 = pb + mul(Rb, v3(md.haa_off[0] * sx, md.haa_off[1] * sy, md.haa_off[2]));
+		const V3 a1 = Rb.c0;
+		const M3 R1 = mul(Rb, rot_x(q1));
+		const V3 o2 = o1 + mul(R1, v3(md.hfe_off[0], md.hfe_off[1] * sy, md.hfe_off[2]));
+		const V3 a2 = R1.c1;
+		const M3 R2 = mul(R1, rot_y(q2));
+		const V3 o3 = o2 + mul(R2, v3(md.kfe_off[0], md.kfe_off[1] * sy, md.kfe_off[2]));
+		const V3 a3 = R2.c1;
+		const M3 R3 = mul(R2, rot_y(q3));
+		// velocities / bias accelerations (u_dot = 0); the base origin has zero bias acceleration
+		const V3 acc_o1 = cross(w0, cross(w0, o1 - pb));
+		const V3 w1 = w0 + a1 * d1;
+		const V3 al1 = cross(w0, a1) * d1;
+		const V3 acc_o2 = pt_acc(acc_o1, al1, w1, o2 - o1);
+		const V3 w2 = w1 + a2 * d2;
+		const V3 al2 = al1 + cross(w1, a2) * d2;
+		const V3 acc_o3 = pt_acc(acc_o2, al2, w2, o3 - o2);
+		const V3 w3 = w2 + a3 * d3;
+		const V3 al3 = al2 + cross(w2, a3) * d3;
+
+		// this lane's point (body COM or foot), frame, twist and ancestor depth
+		V3 r, org, om, al, acc_o;
+		M3 R;
+		double mass = 0.0;
+		V3 In = zero;
+		int depth;  // number of leg joints above the point
+		if (lane == 0) {
+			r = pb, org = pb, om = w0, al = zero, acc_o = zero, R = Rb, depth = 0;
+			mass = md.base_mass, In = ld3(md.base_inertia);
+		} else if (link == 0) {
+			org = o1, om = w1, al = al1, acc_o = acc_o1, R = R1, depth = 1;
+			r = o1 + mul(R1, v3(md.hip_com[0], md.hip_com[1] * sy, md.hip_com[2]));
+			mass = md.hip_mass, In = ld3(md.hip_inertia);
+		} else if (link == 1) {
+			org = o2, om = w2, al = al2, acc_o = acc_o2, R = R2, depth = 2;
+			r = o2 + mul(R2, v3(md.thigh_com[0], md.thigh_com[1] * sy, md.thigh_com[2]));
+			mass = md.thigh_mass, In = ld3(md.thigh_inertia);
+		} else {  // shank body or foot point: both ride on the shank frame
+			org = o3, om = w3, al = al3, acc_o = acc_o3, R = R3, depth = 3;
+			r = o3 + mul(R3, isFoot ? ld3(md.foot_off) : ld3(md.shank_com));
+			mass = md.shank_mass, In = ld3(md.shank_inertia);
+		}
+		const V3 acc = pt_acc(acc_o, al, om, r - org);
+		// translational Jacobian of r: base angular | base linear | ancestor joints
+		const V3 d = r - pb;
+		const V3 jc1 = cross(a1, r - o1), jc2 = cross(a2, r - o2), jc3 = cross(a3, r - o3);
+		if (isFoot) {
+			double *J = Jfg + ((size_t)inst * 4 + leg) * 3 * NU_;
+			for (int i = 0; i < 3 * NU_; ++i)
+				J[i] = 0.0;
+			// -skew(d)
+			J[0 * NU_ + 1] = d.z, J[0 * NU_ + 2] = -d.y;
+			J[1 * NU_ + 0] = -d.z, J[1 * NU_ + 2] = d.x;
+			J[2 * NU_ + 0] = d.y, J[2 * NU_ + 1] = -d.x;
+			J[0 * NU_ + 3] = 1.0, J[1 * NU_ + 4] = 1.0, J[2 * NU_ + 5] = 1.0;
+			J[0 * NU_ + 6 + leg] = jc1.x, J[1 * NU_ + 6 + leg] = jc1.y, J[2 * NU_ + 6 + leg] = jc1.z;
+			J[0 * NU_ + 10 + leg] = jc2.x, J[1 * NU_ + 10 + leg] = jc2.y, J[2 * NU_ + 10 + leg] = jc2.z;
+			J[0 * NU_ + 14 + leg] = jc3.x, J[1 * NU_ + 14 + leg] = jc3.y, J[2 * NU_ + 14 + leg] = jc3.z;
+			double *o = Jdug + ((size_t)inst * 4 + leg) * 3;
+			o[0] = acc.x, o[1] = acc.y, o[2] = acc.z;
+			o = fpg + ((size_t)inst * 4 + leg) * 3;
+			o[0] = r.x, o[1] = r.y, o[2] = r.z;
+		} else {
+			double *B = sm + lane * BSTR;
+			double *Jv = B + JV, *Jw = B + JW;
+			Jv[0 * NU_ + 1] = d.z, Jv[0 * NU_ + 2] = -d.y;
+			Jv[1 * NU_ + 0] = -d.z, Jv[1 * NU_ + 2] = d.x;
+			Jv[2 * NU_ + 0] = d.y, Jv[2 * NU_ + 1] = -d.x;
+			Jv[0 * NU_ + 3] = 1.0, Jv[1 * NU_ + 4] = 1.0, Jv[2 * NU_ + 5] = 1.0;
+			Jw[0 * NU_ + 0] = 1.0, Jw[1 * NU_ + 1] = 1.0, Jw[2 * NU_ + 2] = 1.0;
+			if (depth >= 1) {
+				const int cj = 6 + leg;
+				Jv[0 * NU_ + cj] = jc1.x, Jv[1 * NU_ + cj] = jc1.y, Jv[2 * NU_ + cj] = jc1.z;
+				Jw[0 * NU_ + cj] = a1.x, Jw[1 * NU_ + cj] = a1.y, Jw[2 * NU_ + cj] = a1.z;
+			}
+			if (depth >= 2) {
+				const int cj = 10 + leg;
+				Jv[0 * NU_ + cj] = jc2.x, Jv[1 * NU_ + cj] = jc2.y, Jv[2 * NU_ + cj] = jc2.z;
+				Jw[0 * NU_ + cj] = a2.x, Jw[1 * NU_ + cj] = a2.y, Jw[2 * NU_ + cj] = a2.z;
+			}
+			if (depth >= 3) {
+				const int cj = 14 + leg;
+				Jv[0 * NU_ + cj] = jc3.x, Jv[1 * NU_ + cj] = jc3.y, Jv[2 * NU_ + cj] = jc3.z;
+				Jw[0 * NU_ + cj] = a3.x, Jw[1 * NU_ + cj] = a3.y, Jw[2 * NU_ + cj] = a3.z;
+			}
+			// world inertia I_w = R diag(In) R'
+			const V3 s0 = R.c0 * In.x, s1 = R.c1 * In.y, s2 = R.c2 * In.z;
+			double Iw[9];
+			Iw[0] = s0.x * R.c0.x + s1.x * R.c1.x + s2.x * R.c2.x;
+			Iw[1] = s0.x * R.c0.y + s1.x * R.c1.y + s2.x * R.c2.y;
+			Iw[2] = s0.x * R.c0.z + s1.x * R.c1.z + s2.x * R.c2.z;
+			Iw[3] = s0.y * R.c0.x + s1.y * R.c1.x + s2.y * R.c2.x;
+			Iw[4] = s0.y * R.c0.y + s1.y * R.c1.y + s2.y * R.c2.y;
+			Iw[5] = s0.y * R.c0.z + s1.y * R.c1.z + s2.y * R.c2.z;
+			Iw[6] = s0.z * R.c0.x + s1.z * R.c1.x + s2.z * R.c2.x;
+			Iw[7] = s0.z * R.c0.y + s1.z * R.c1.y + s2.z * R.c2.y;
+			Iw[8] = s0.z * R.c0.z + s1.z * R.c1.z + s2.z * R.c2.z;
+			for (int i = 0; i < 9; ++i)
+				B[IW + i] = Iw[i];
+			// bias wrench: f = m a (- m g), t = I_w alpha + w x (I_w w)
+			V3 wf = acc * mass;
+			if (include_gravity)
+				wf.z += mass * md.gravity;
+			const V3 Iom = v3(Iw[0] * om.x + Iw[1] * om.y + Iw[2] * om.z, Iw[3] * om.x + Iw[4] * om.y + Iw[5] * om.z,
+					  Iw[6] * om.x + Iw[7] * om.y + Iw[8] * om.z);
+			const V3 Ial = v3(Iw[0] * al.x + Iw[1] * al.y + Iw[2] * al.z, Iw[3] * al.x + Iw[4] * al.y + Iw[5] * al.z,
+					  Iw[6] * al.x + Iw[7] * al.y + Iw[8] * al.z);
+			const V3 wt = Ial + cross(om, Iom);
+			B[WF + 0] = wf.x, B[WF + 1] = wf.y, B[WF + 2] = wf.z;
+			B[WT + 0] = wt.x, B[WT + 1] = wt.y, B[WT + 2] = wt.z;
+			B[MS] = mass;
+		}
+	}
+	__syncthreads();
+	// I_w J_w per body (3 x 18)
+	for (int e = lane; e < NB * 54; e += kWave) {
+		const int b = e / 54, rem = e - b * 54, k = rem / NU_, j = rem - k * NU_;
+		const double *B = sm + b * BSTR;
+		sm[b * BSTR + IJ + rem] =
+			B[IW + 3 * k] * B[JW + j] + B[IW + 3 * k + 1] * B[JW + NU_ + j] + B[IW + 3 * k + 2] * B[JW + 2 * NU_ + j];
+	}
+	__syncthreads();
+
+	// ---- phase 2: M = sym( sum_b m Jv'Jv + Jw' (I_w Jw) ),  h = sum_b Jv' f + Jw' t ----
+	for (int e = lane; e < NU_ * NU_; e += kWave) {
+		const int i = e / NU_, j = e - i * NU_;
+		double sij = 0.0, sji = 0.0;
+		for (int b = 0; b < NB; ++b) {
+			const double *B = sm + b * BSTR;
+			const double mass = B[MS];
+#pragma unroll
+			for (int k = 0; k < 3; ++k) {
+				const double jvi = B[JV + k * NU_ + i], jvj = B[JV + k * NU_ + j];
+				sij = fma(mass * jvi, jvj, sij);
+				sji = fma(mass * jvj, jvi, sji);
+				sij = fma(B[JW + k * NU_ + i], B[IJ + k * NU_ + j], sij);
+				sji = fma(B[JW + k * NU_ + j], B[IJ + k * NU_ + i], sji);
+			}
+		}
+		Mg[(size_t)inst * NU_ * NU_ + e] = 0.5 * (sij + sji);
+	}
+	if (lane < NU_) {
+		double acc = 0.0;
+		for (int b = 0; b < NB; ++b) {
+			const double *B = sm + b * BSTR;
+#pragma unroll
+			for (int k = 0; k < 3; ++k) {
+				acc = fma(B[JV + k * NU_ + lane], B[WF + k], acc);
+				acc = fma(B[JW + k * NU_ + lane], B[WT + k], acc);
+			}
+		}
+		hg[(size_t)inst * NU_ + lane] = acc;
+	}
+	if (Jbg)  // spatial velocity of the base origin in W is u[0:6] itself (dynamics.cpp:213-228)
+		for (int e = lane; e < 6 * NU_; e += kWave)
+			Jbg[(size_t)inst * 6 * NU_ + e] = (e / NU_ == e % NU_) ? 1.0 : 0.0;
+}
+
+}  // namespace hoqp

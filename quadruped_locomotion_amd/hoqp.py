@@ -33,7 +33,7 @@ STATUS_NONFINITE = 0x08
 EXPORTS = (
     "hoqp_default_config", "hoqp_create", "hoqp_destroy", "hoqp_last_error_string",
     "hoqp_solve_tasks_batched", "hoqp_solve_wbc_batched", "hoqp_solve_tasks_host", "hoqp_solve_wbc_host",
-    "hoqp_wbc_poststep_batched", "hoqp_synchronize",
+    "hoqp_default_quadruped_model", "hoqp_wbc_dynamics_batched", "hoqp_wbc_poststep_batched", "hoqp_synchronize",
     "hoqp_kernel_time_ms", "hoqp_selftest", "hoqp_lds_bytes",
 )
 
@@ -47,6 +47,13 @@ class Config(C.Structure):
                 ("mu", C.c_double), ("tau_max", C.c_double), ("tau_min", C.c_double),
                 ("kp_swing", C.c_double), ("kv_swing", C.c_double), ("kp_base", C.c_double),
                 ("kv_base", C.c_double), ("kv_rot", C.c_double)]
+
+
+class QuadrupedModel(C.Structure):
+    _fields_ = [("base_mass", C.c_double), ("hip_mass", C.c_double), ("thigh_mass", C.c_double),
+                ("shank_mass", C.c_double)] + [(n, C.c_double * 3) for n in (
+                    "base_inertia", "hip_inertia", "thigh_inertia", "shank_inertia", "haa_off", "hfe_off", "kfe_off",
+                    "foot_off", "hip_com", "thigh_com", "shank_com")] + [("gravity", C.c_double)]
 
 
 class TaskBatch(C.Structure):
@@ -102,6 +109,10 @@ def load_library():
         lib.hoqp_solve_tasks_batched.argtypes = [C.c_void_p, C.POINTER(TaskBatch), C.POINTER(ResultBatch), C.c_void_p]
         lib.hoqp_solve_wbc_batched.argtypes = [C.c_void_p, C.POINTER(WbcInputs), C.POINTER(WbcOutputs), C.c_void_p]
         lib.hoqp_synchronize.argtypes = [C.c_void_p, C.c_void_p]
+        lib.hoqp_default_quadruped_model.argtypes = [C.POINTER(QuadrupedModel)]
+        lib.hoqp_default_quadruped_model.restype = None
+        lib.hoqp_wbc_dynamics_batched.argtypes = [C.c_void_p, C.POINTER(QuadrupedModel), C.c_int, C.c_void_p, C.c_void_p,
+                                                  C.c_int] + [C.c_void_p] * 7
         lib.hoqp_wbc_poststep_batched.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double] + [C.c_void_p] * 8
         lib.hoqp_kernel_time_ms.argtypes = [C.c_void_p, C.c_int, _dp, _ip]
         lib.hoqp_selftest.argtypes = [C.c_void_p]
@@ -268,6 +279,25 @@ class HoQpSolver:
         """dict of numpy arrays (anymal_model.make_wbc_inputs) -> dict of device tensors."""
         t = self.torch
         return {k: t.as_tensor(v).contiguous().to(self.device) for k, v in inp.items()}
+
+    def wbc_dynamics(self, q, u, include_gravity=True, model=None, with_Jb=True):
+        """Dynamics terms of the batch of states (hoqp_wbc_dynamics_batched): q [B, 19], u [B, 18]
+        float64 CUDA tensors -> dict with M, h, Jfoot, Jdotu, footpos (, Jb) in the layout solve_wbc takes."""
+        t = self.torch
+        B = q.shape[0]
+        assert q.dtype == t.float64 and q.is_cuda and q.is_contiguous() and tuple(q.shape) == (B, 19)
+        assert u.dtype == t.float64 and u.is_cuda and u.is_contiguous() and tuple(u.shape) == (B, 18)
+        kw = dict(dtype=t.float64, device=q.device)
+        out = {"M": t.empty((B, 18, 18), **kw), "h": t.empty((B, 18), **kw), "Jfoot": t.empty((B, 4, 3, 18), **kw),
+               "Jdotu": t.empty((B, 4, 3), **kw), "footpos": t.empty((B, 4, 3), **kw)}
+        if with_Jb:
+            out["Jb"] = t.empty((B, 6, 18), **kw)
+        self._check(self.lib.hoqp_wbc_dynamics_batched(
+            self.h, C.byref(model) if model is not None else None, B, q.data_ptr(), u.data_ptr(),
+            1 if include_gravity else 0, out["M"].data_ptr(), out["h"].data_ptr(), out["Jfoot"].data_ptr(),
+            out["Jdotu"].data_ptr(), out["footpos"].data_ptr(), out["Jb"].data_ptr() if with_Jb else None,
+            self._stream()), "hoqp_wbc_dynamics_batched")
+        return out
 
     def wbc_poststep(self, dt, kp, kd, qdd, tau_ff, q_j, qd_j, q_cmd, qd_cmd, tau_cmd=None):
         """In-place integrator update of (q_cmd, qd_cmd) and the PD + feed-forward torque

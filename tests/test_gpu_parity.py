@@ -254,3 +254,57 @@ def test_wbc_poststep(solver_factory, oracle):
     s.synchronize()
     q4, qd4, _ = oracle.wbc_poststep(2.5e-3, 0.0, 0.0, a["qdd"], a["tau_ff"], a["q_j"], a["qd_j"], q_ref, qd_ref)
     assert np.abs(d["q_cmd"].cpu().numpy() - q4).max() <= 1e-13
+
+
+@pytest.mark.parametrize("gravity", [True, False])
+def test_wbc_dynamics_producer(solver_factory, gravity):
+    """N1 (dynamics-terms producer): the device kernel against the numpy model it restates
+    (quadruped_locomotion_amd/anymal_model.py; the reference's producer is Drake on a URDF that is
+    not available, so the MODEL is parity unpinned).  Same formulas, different summation order:
+    1e-12 relative to the largest entry of each array."""
+    import torch
+
+    st = am.sample_states(512, 77, "trot")
+    q, u = st["q"], st["u"]
+    M, h, Jf, Jdu, fp, Jb = am.dynamics_terms(q, u, include_gravity=gravity)
+    s = solver_factory("reference")
+    out = s.wbc_dynamics(torch.as_tensor(q).contiguous().cuda(), torch.as_tensor(u).contiguous().cuda(),
+                         include_gravity=gravity)
+    s.synchronize()
+    for name, ref in (("M", M), ("h", h), ("Jfoot", Jf), ("Jdotu", Jdu), ("footpos", fp), ("Jb", Jb)):
+        got = out[name].cpu().numpy()
+        assert got.shape == ref.shape, name
+        scale = max(1.0, np.abs(ref).max())
+        assert np.abs(got - ref).max() <= 1e-12 * scale, (name, np.abs(got - ref).max())
+
+
+def test_wbc_device_pipeline(solver_factory, oracle):
+    """state -> dynamics terms (N1) -> WBC solve -> post-solve step (N2), all on the device; the
+    solve on device-produced inputs matches the oracle on the numpy-produced inputs."""
+    import torch
+
+    st = am.sample_states(256, 78, "stance")
+    inp = am.make_wbc_inputs(st)
+    s = solver_factory("reference")
+    dq = torch.as_tensor(st["q"]).contiguous().cuda()
+    du = torch.as_tensor(st["u"]).contiguous().cuda()
+    dyn = s.wbc_dynamics(dq, du)
+    dinp = s.to_device(inp)
+    for k in ("M", "h", "Jfoot", "Jdotu", "footpos", "Jb"):
+        dinp[k] = dyn[k]
+    out = s.solve_wbc(dinp)
+    q_cmd = dq[:, 7:19].contiguous().clone()
+    qd_cmd = du[:, 6:18].contiguous().clone()
+    tau_cmd = torch.empty_like(q_cmd)
+    s.wbc_poststep(2.5e-3, 40.0, 1.0, out["qdd"], out["tau"], dq[:, 7:19].contiguous(), du[:, 6:18].contiguous(),
+                   q_cmd, qd_cmd, tau_cmd)
+    s.synchronize()
+    ref, rc = oracle.wbc_solve_batch(inp, oracle.default_cfg("reference"), oracle.default_wbc_params("reference"), threads=8)
+    assert rc == 0
+    _close(out["x"].cpu().numpy(), ref["x"], "x")
+    _close(out["tau"].cpu().numpy(), ref["tau"], "tau")
+    # first cycle from the measured state: the PD terms only see dt-sized offsets
+    qd_ref = st["u"][:, 6:18] + 2.5e-3 * ref["qdd"]
+    q_ref = st["q"][:, 7:19] + 2.5e-3 * qd_ref
+    tau_ref = 40.0 * (q_ref - st["q"][:, 7:19]) + 1.0 * (qd_ref - st["u"][:, 6:18]) + ref["tau"]
+    _close(tau_cmd.cpu().numpy(), tau_ref, "tau_cmd")
