@@ -189,6 +189,11 @@ int hoqp_wbc_dynamics_batched(hoqp_handle *h, const hoqp_quadruped_model *model,
 			      const double *u, int include_gravity, double *M, double *hvec, double *Jfoot,
 			      double *Jdotu, double *footpos, double *Jb, void *stream);
 
+/* Host-buffer variant of hoqp_wbc_dynamics_batched (all pointers are host pointers; blocks). */
+int hoqp_wbc_dynamics_host(hoqp_handle *h, const hoqp_quadruped_model *model, int batch, const double *q,
+			   const double *u, int include_gravity, double *M, double *hvec, double *Jfoot, double *Jdotu,
+			   double *footpos, double *Jb);
+
 /* Post-solve step of the whole-body controller, batched and device resident:
  * the two forward-Euler integrations that turn the joint acceleration command into velocity and
  * position commands (WholeBodyController::SetJointCmdFromIntegrators,

@@ -359,15 +359,35 @@ public:
 			Jb_.clear();
 	}
 
+	// Instead of SetModelDynamics: let CalcJointCmd produce M, h, J, ... from (q, u) itself, as
+	// the reference's UpdateModelDynamics does (ho_qp_controller.cpp:89-114), with the library's
+	// quadruped model (hoqp_wbc_dynamics_host; model == nullptr: the default parameters).
+	void UseBuiltinDynamics(const hoqp_quadruped_model *model = nullptr, bool include_gravity = true)
+	{
+		builtin_ = true;
+		include_gravity_ = include_gravity;
+		if (model)
+			model_ = *model;
+		else
+			hoqp_default_quadruped_model(&model_);
+	}
+
 	void CalcJointCmd(const hoqp::VectorXd &q, const hoqp::VectorXd &u)
 	{
-		if (M_.empty())
-			throw std::runtime_error("HoQpController: SetModelDynamics was not called");
 		for (int i = 0; i < 19; ++i)
 			q_[i] = q(i);
 		for (int i = 0; i < 18; ++i)
 			u_[i] = u(i);
 		auto hd = hoqp::thread_handle();
+		if (builtin_) {
+			M_.resize(324), h_.resize(18), Jfoot_.resize(216), Jdotu_.resize(12), footpos_.resize(12), Jb_.resize(108);
+			hoqp::check(*hd, hoqp_wbc_dynamics_host(hd->h, &model_, 1, q_.data(), u_.data(), include_gravity_ ? 1 : 0,
+							       M_.data(), h_.data(), Jfoot_.data(), Jdotu_.data(),
+							       footpos_.data(), Jb_.data()),
+				    "hoqp_wbc_dynamics_host");
+		}
+		if (M_.empty())
+			throw std::runtime_error("HoQpController: neither SetModelDynamics nor UseBuiltinDynamics was called");
 		hoqp_wbc_inputs in{};
 		in.batch = 1;
 		in.M = M_.data();
@@ -413,6 +433,8 @@ public:
 private:
 	std::vector<double> M_, h_, Jfoot_, Jdotu_, footpos_, Jb_, base_cmd_, leg_cmd_, q_, u_;
 	int contact_[4];
+	bool builtin_ = false, include_gravity_ = true;
+	hoqp_quadruped_model model_{};
 	int flags_[5] = {0, 0, 0, 0, 0};
 	int status_ = 0;
 	hoqp::VectorXd solution_, q_j_ddot_cmd_, tau_cmd_;

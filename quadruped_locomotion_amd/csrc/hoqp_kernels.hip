@@ -884,6 +884,42 @@ extern "C" int hoqp_solve_wbc_host(hoqp_handle *h, const hoqp_wbc_inputs *in, co
 	return 0;
 }
 
+extern "C" int hoqp_wbc_dynamics_host(hoqp_handle *h, const hoqp_quadruped_model *model, int batch, const double *q,
+				      const double *u, int include_gravity, double *M, double *hvec, double *Jfoot,
+				      double *Jdotu, double *footpos, double *Jb)
+{
+	if (!h)
+		return -1;
+	if (batch < 0)
+		return fail(h, -1, "negative batch");
+	if (!q || !u || !M || !hvec || !Jfoot || !Jdotu || !footpos)
+		return fail(h, -1, "hoqp_wbc_dynamics_host: null array");
+	HIP_OK(h, hipSetDevice(h->cfg.device));
+	DevBuf buf;
+	const size_t B = batch;
+	const double *dq = nullptr, *du = nullptr;
+	HIP_OK(h, buf.up(q, B * 19, &dq));
+	HIP_OK(h, buf.up(u, B * 18, &du));
+	double *dM = nullptr, *dh = nullptr, *dJf = nullptr, *dJdu = nullptr, *dfp = nullptr, *dJb = nullptr;
+	HIP_OK(h, buf.out(M, B * 324, &dM));
+	HIP_OK(h, buf.out(hvec, B * 18, &dh));
+	HIP_OK(h, buf.out(Jfoot, B * 216, &dJf));
+	HIP_OK(h, buf.out(Jdotu, B * 12, &dJdu));
+	HIP_OK(h, buf.out(footpos, B * 12, &dfp));
+	HIP_OK(h, buf.out(Jb, B * 108, &dJb));
+	int rc = hoqp_wbc_dynamics_batched(h, model, batch, dq, du, include_gravity, dM, dh, dJf, dJdu, dfp, dJb, nullptr);
+	if (rc)
+		return rc;
+	HIP_OK(h, hipStreamSynchronize(nullptr));
+	HIP_OK(h, down(M, (const double *)dM, B * 324));
+	HIP_OK(h, down(hvec, (const double *)dh, B * 18));
+	HIP_OK(h, down(Jfoot, (const double *)dJf, B * 216));
+	HIP_OK(h, down(Jdotu, (const double *)dJdu, B * 12));
+	HIP_OK(h, down(footpos, (const double *)dfp, B * 12));
+	HIP_OK(h, down(Jb, (const double *)dJb, B * 108));
+	return 0;
+}
+
 extern "C" int hoqp_synchronize(hoqp_handle *h, void *stream)
 {
 	if (!h)

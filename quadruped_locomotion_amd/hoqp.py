@@ -33,7 +33,7 @@ STATUS_NONFINITE = 0x08
 EXPORTS = (
     "hoqp_default_config", "hoqp_create", "hoqp_destroy", "hoqp_last_error_string",
     "hoqp_solve_tasks_batched", "hoqp_solve_wbc_batched", "hoqp_solve_tasks_host", "hoqp_solve_wbc_host",
-    "hoqp_default_quadruped_model", "hoqp_wbc_dynamics_batched", "hoqp_wbc_poststep_batched", "hoqp_synchronize",
+    "hoqp_default_quadruped_model", "hoqp_wbc_dynamics_batched", "hoqp_wbc_dynamics_host", "hoqp_wbc_poststep_batched", "hoqp_synchronize",
     "hoqp_kernel_time_ms", "hoqp_selftest", "hoqp_lds_bytes",
 )
 

@@ -103,6 +103,13 @@ int main(int argc, char **argv)
 		print_vec("x", ctl.GetSolution());
 		const int *fl = ctl.GetSolutionValidFlags();
 		std::printf("flags %d %d %d %d %d status %d\n", fl[0], fl[1], fl[2], fl[3], fl[4], ctl.GetStatus());
+		// the same cycle with the dynamics terms produced from (q, u) by the library
+		control::HoQpController ctl2;
+		ctl2.UseBuiltinDynamics();
+		ctl2.SetBaseCmd(bc, bd, bdd);
+		ctl2.SetLegCmd(lc, ld, ldd, cp);
+		ctl2.CalcJointCmd(q, u);
+		print_vec("tau_builtin", ctl2.GetJointTorqueCmd());
 	}
 	return 0;
 }

@@ -79,6 +79,9 @@ def test_shim_controller(tmp_path, oracle):
     n = int(ref["n"][0])
     assert got["x"].size == n
     assert np.all(np.abs(got["x"] - ref["x"][0][:n]) <= 1e-6 * np.maximum(1.0, np.abs(ref["x"][0][:n])))
+    # UseBuiltinDynamics: the library's own producer gives the same cycle (same model as the fixture)
+    tb = [np.array(l.split()[2:], dtype=float) for l in out if l.startswith("tau_builtin")][0]
+    assert np.all(np.abs(tb - ref["tau"][0]) <= 1e-6 * np.maximum(1.0, np.abs(ref["tau"][0])))
     fl = [l for l in out if l.startswith("flags")][0].split()
     assert int(fl[7]) == 0
     assert [int(v) for v in fl[1:6]][0] == 1
