@@ -179,7 +179,7 @@ def _lowrank(rng, B, m, n, r):
 
 
 @pytest.mark.parametrize("mode", ["reference", "paper"])
-@pytest.mark.parametrize("case", ["wide_many_dependent", "tall_rank_deficient", "few_dependent", "n32"])
+@pytest.mark.parametrize("case", ["wide_many_dependent", "tall_rank_deficient", "few_dependent", "n32", "max_shape"])
 def test_structured_tasks(solver_factory, oracle, mode, case):
     """Rank-deficient and extreme-shape levels: the dependent-row paths of the least squares
     (low-rank correction for <= 8 dependent rows, semi-normal equations beyond), the fallback of a
@@ -201,6 +201,12 @@ def test_structured_tasks(solver_factory, oracle, mode, case):
         tasks = [{"A": _lowrank(rng, B, 6, n, 4), "b": rng.normal(size=(B, 6))},
                  {"D": rng.normal(size=(B, 5, n)), "f": rng.normal(size=(B, 5)) + 0.5},
                  {"A": rng.normal(size=(B, 14, n)), "b": rng.normal(size=(B, 14))}]
+    elif case == "max_shape":              # the limits of hoqp.h: n = 32, 64 inequality rows, 32 equality rows
+        n = 32
+        B = 16
+        tasks = [{"A": rng.normal(size=(B, 6, n)), "b": rng.normal(size=(B, 6))},
+                 {"D": rng.normal(size=(B, 64, n)), "f": rng.normal(size=(B, 64)) + 2.0},
+                 {"A": rng.normal(size=(B, 32, n)), "b": rng.normal(size=(B, 32))}]
     else:                                   # n = 32
         n = 32
         tasks = [{"A": rng.normal(size=(B, 8, n)), "b": rng.normal(size=(B, 8))},
