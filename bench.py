@@ -157,7 +157,7 @@ def main():
         kern_s = kern_ms * 1e-3
         achieved_gbs = ALG_BYTES_PER_SOLVE * args.batch / kern_s / 1e9 if kern_s > 0 else 0.0
         # HBM bytes per launch of the dominant kernel from the committed PMC pass of this same
-        # command (tools_profile.sh; separate --pmc runs).  Only reported for the profiled
+        # command (tools/profile.sh; separate --pmc runs).  Only reported for the profiled
         # workload; FETCH_SIZE is uncalibrated for 8-byte-per-lane loads on gfx950.
         traffic, traffic_src = None, None
         try:

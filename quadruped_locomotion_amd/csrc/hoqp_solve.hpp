@@ -928,7 +928,7 @@ __device__ __forceinline__ void project_task(const double *__restrict__ rows_g, 
 // 16 x K operand tile of v_mfma_f64_16x16x4_f64; [Z | x] (n x (n_z + 1)) is the other operand,
 // kept in registers for the whole level:  bm[kb][cb] = B[k = 4 kb + lane/16][j = 16 cb + lane%16]
 // with B[k][j] = Z[k][j] (j < n_z), x[k] (j == n_z), 0 otherwise / for k >= n.
-// Operand layout of the instruction on gfx950 (probed, tools_mfma/mfma_layout.hip):
+// Operand layout of the instruction on gfx950 (probed, tools/mfma/mfma_layout.hip):
 //   A[i = lane%16][k = lane/16],  B[k = lane/16][j = lane%16],  D[i = lane/16 + 4 r][j = lane%16].
 // Outputs as in project_task: (A Z) rows -> TV / G, right-hand side minus (a_r x) -> rhs / g.
 // ---------------------------------------------------------------------------

@@ -1,6 +1,7 @@
 #!/bin/bash
 # one GPU round trip: parity tests, bench (both modes), section profile.  Stops at the first failure.
 set -e
+cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 timeout -k 10 600 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > gpurun_out/gpu_tests.log 2>&1 || { tail -30 gpurun_out/gpu_tests.log; exit 1; }
 tail -3 gpurun_out/gpu_tests.log

@@ -1,6 +1,7 @@
 #!/bin/bash
 # the other SURVEY 8d configurations (C3 trot mix 65536, C5 three-contact paper, large batch)
 set -e
+cd "$(dirname "$0")/.."
 mkdir -p gpurun_out/configs
 run() { name=$1; shift; timeout -k 10 300 python bench.py --no-cpu-baseline --steps 20 --warmup 3 "$@" > gpurun_out/configs/$name.json; python3 -c "
 import json,sys; d=json.load(open('gpurun_out/configs/$name.json')); print('$name', round(d['value']), 'solves/s', round(d['ms_per_step'],3), 'ms/step', d['solver'])"; }

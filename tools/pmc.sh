@@ -1,6 +1,7 @@
 #!/bin/bash
 # PMC passes over the bench (one counter group per run, as the pool rules require)
 set -e
+cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/pmc
 mkdir -p $OUT
