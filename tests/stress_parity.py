@@ -1,0 +1,47 @@
+"""Large randomized parity sweep (not collected by pytest: run by hand on a GPU box):
+    python tests/stress_parity.py [states_per_case [seed_offset]]
+HIP path against the CPU oracle on every contact mode and both semantics; prints the worst
+element-wise relative errors, the number of instances over the 1e-6 tolerance (tests/stress_instance.py
+looks at one of them level by level), status counts and flag / active-mask disagreements outside the 1e-7 band."""
+import sys
+import os
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from quadruped_locomotion_amd import anymal_model as am  # noqa: E402
+from quadruped_locomotion_amd import hoqp  # noqa: E402
+from oracle import oracle  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+SEED0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+bad = 0
+for mode in ("reference", "paper"):
+    s = hoqp.HoQpSolver(hoqp.default_config(mode))
+    for kind, seed in (("stance", 11), ("trot", 12), ("three", 13)):
+        inp = am.make_wbc_inputs(am.sample_states(N, seed + SEED0, kind))
+        out = s.solve_wbc(s.to_device(inp))
+        s.synchronize()
+        o = {k: v.cpu().numpy() for k, v in out.items()}
+        ref, rc = oracle.wbc_solve_batch(inp, oracle.default_cfg(mode), oracle.default_wbc_params(mode), threads=16)
+        errs, over = {}, np.zeros(N, dtype=bool)
+        for key, width in (("x", 30), ("qdd", 12), ("tau", 12), ("v", 40), ("level_res", 5)):
+            r = ref[key][:, :width] if key == "v" else ref[key]
+            e = (np.abs(o[key] - r) / np.maximum(1.0, np.abs(r))).reshape(N, -1).max(axis=1)
+            errs[key] = float(e.max())
+            over |= e > 1e-6
+        # the same x error measured against the size of the whole solution vector
+        xrel = float((np.abs(o["x"] - ref["x"]).max(axis=1) / np.maximum(1.0, np.abs(ref["x"]).max(axis=1))).max())
+        band = 1e-7
+        clear = (np.abs(ref["eq_res_max"] - 1e-7) > band * 0.5) & (np.abs(ref["ineq_viol_max"]) > band)
+        flag_diff = int(((o["flags"] != ref["flags"]) & clear).sum())
+        nst = int((o["status"] != 0).sum())
+        nref = int((ref["status"] != 0).sum())
+        worst = max(errs.values())
+        ok = worst <= 1e-6 and nst == 0 and flag_diff == 0 and rc == 0
+        bad += not ok
+        print(f"{mode:9s} {kind:6s} N={N} rc={rc} worst={worst:.2e} {errs} gpu_status!=0:{nst} oracle_status!=0:{nref} "
+              f"flag_diff:{flag_diff} over_1e-6:{int(over.sum())} of {N} (indices {np.flatnonzero(over)[:8].tolist()}) "
+              f"x_err/|x|_inf:{xrel:.2e} iters_max:{int(o['iters'].max())} {'OK' if ok else 'FAIL'}", flush=True)
+print("ALL OK" if bad == 0 else f"{bad} case(s) FAILED")
+sys.exit(1 if bad else 0)
