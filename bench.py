@@ -34,13 +34,24 @@ ALG_BYTES_PER_SOLVE = 8 * 76 * 31 + 664
 ALG_FLOPS_PER_SOLVE = 210_984
 
 
-def cpu_baseline(inp, mode, sample, threads):
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(inp, mode, sample, threads, prm_kw, detail=False):
     """The oracle ("port") timed on the host cores over a bounded sample."""
     from oracle import oracle as orc
 
     orc.build()
     sub = {k: v[:sample] for k, v in inp.items()}
-    cfg, prm = orc.default_cfg(mode), orc.default_wbc_params(mode)
+    cfg, prm = orc.default_cfg(mode), orc.default_wbc_params(mode, **prm_kw)
     orc.wbc_solve_batch({k: v[:8] for k, v in sub.items()}, cfg, prm, threads=threads)  # warm
     reps, t0 = 0, time.perf_counter()
     while True:
@@ -49,9 +60,25 @@ def cpu_baseline(inp, mode, sample, threads):
         dt = time.perf_counter() - t0
         if dt > 10.0 or reps >= 50:
             break
-    return dict(value=sample * reps / dt, unit="solves/s", cores=threads, kind="port",
-                sample=f"{reps} passes over the first {sample} states of the same batch, "
-                       f"oracle/hoqp_oracle.c (-O3, OpenMP {threads} threads); Drake/Eigen reference unbuildable")
+    res = dict(value=sample * reps / dt, unit="solves/s", cores=threads, kind="port",
+               sample=f"{reps} passes over the first {sample} states of the same batch, "
+                      f"oracle/hoqp_oracle.c (-O3, OpenMP {threads} threads); Drake/Eigen reference unbuildable",
+               cpu_model=cpu_model())
+    if detail:
+        # SURVEY.md 8(d) CPU baseline (i): one thread, configs[0] (the nominal standing state),
+        # 10^4 repetitions, per-solve latency
+        from quadruped_locomotion_amd import anymal_model as am
+
+        one = am.make_wbc_inputs(am.standing_state())
+        lat = np.empty(10000)
+        for i in range(lat.size):
+            a = time.perf_counter()
+            orc.wbc_solve_batch(one, cfg, prm, threads=1)
+            lat[i] = time.perf_counter() - a
+        res["single_thread_c1"] = dict(solves_per_s=float(1.0 / np.median(lat)), median_us=float(np.median(lat) * 1e6),
+                                       p99_us=float(np.percentile(lat, 99) * 1e6), repetitions=int(lat.size),
+                                       note="includes the ctypes call and state packing of one state")
+    return res
 
 
 def main():
@@ -65,6 +92,10 @@ def main():
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=512)
+    ap.add_argument("--mu", type=float, default=None, help="friction coefficient (default: the reference's)")
+    ap.add_argument("--tau-max", type=float, default=None, help="joint torque limit, symmetric (default: the reference's)")
+    ap.add_argument("--cpu-detail", action="store_true",
+                    help="also time the oracle single-threaded on configs[0] (10^4 repetitions)")
     ap.add_argument("--no-gather", action="store_true", help="skip the collection of results on rank 0")
     ap.add_argument("--gather-every-step", action="store_true",
                     help="gather solutions to rank 0 inside every timed step (default: once, after the timed loop)")
@@ -88,7 +119,12 @@ def main():
     from quadruped_locomotion_amd import hoqp
 
     torch.cuda.set_device(local_rank)
-    solver = hoqp.HoQpSolver(hoqp.default_config(args.mode, device=local_rank))
+    prm_kw = {}
+    if args.mu is not None:
+        prm_kw["mu"] = args.mu
+    if args.tau_max is not None:
+        prm_kw.update(tau_max=args.tau_max, tau_min=-args.tau_max)
+    solver = hoqp.HoQpSolver(hoqp.default_config(args.mode, device=local_rank, **prm_kw))
     inp = am.make_wbc_inputs(am.sample_states(args.batch, args.seed + rank, args.contact))
     dinp = solver.to_device(inp)
     out = solver.alloc_wbc_outputs(args.batch)
@@ -184,7 +220,7 @@ def main():
             "config": {"workload": f"configs[1]: {args.batch} randomised {args.contact} states per GPU, "
                                    f"5-level WBC hierarchy, {args.mode} semantics",
                        "batch_per_gpu": args.batch, "semantics": args.mode, "contact": args.contact,
-                       "entry": "hoqp_solve_wbc_batched",
+                       "entry": "hoqp_solve_wbc_batched", "params": prm_kw or "reference defaults",
                        "gather": ("every_step" if args.gather_every_step else "after_loop")
                        if (world > 1 and not args.no_gather) else "none", "gather_ms": gather_ms},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -199,11 +235,14 @@ def main():
             "latency_ms": {"p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99)),
                            "max": float(lat.max()), "batches": int(lat.size)},
             "solver": {"status_nonzero": int((status != 0).sum()), "iters_level1_mean": float(iters[:, 1].mean()),
-                       "iters_max": int(iters.max())},
+                       "iters_max": int(iters.max()),
+                       # active-set steps per instance, summed over the levels: histogram 0,1,2,...
+                       "iters_hist": np.bincount(iters.sum(axis=1).astype(np.int64)).tolist()},
         }
         if not args.no_cpu_baseline and world == 1:
             threads = min(16, os.cpu_count() or 1)
-            res["cpu_baseline"] = cpu_baseline(inp, args.mode, min(args.cpu_sample, args.batch), threads)
+            res["cpu_baseline"] = cpu_baseline(inp, args.mode, min(args.cpu_sample, args.batch), threads, prm_kw,
+                                               detail=args.cpu_detail)
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res))

@@ -16,14 +16,17 @@ from oracle import oracle  # noqa: E402
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 SEED0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 bad = 0
-for mode in ("reference", "paper"):
-    s = hoqp.HoQpSolver(hoqp.default_config(mode))
+C5 = dict(mu=0.2, tau_max=40.0, tau_min=-40.0)   # friction / torque rows go active
+for mode, kw in (("reference", {}), ("paper", {}), ("paper", C5)):
+    s = hoqp.HoQpSolver(hoqp.default_config(mode, **kw))
     for kind, seed in (("stance", 11), ("trot", 12), ("three", 13)):
-        inp = am.make_wbc_inputs(am.sample_states(N, seed + SEED0, kind))
+        if kw and kind != "three":
+            continue
+        inp = am.make_wbc_inputs(am.sample_states(N, seed + SEED0 + (50 if kw else 0), kind))
         out = s.solve_wbc(s.to_device(inp))
         s.synchronize()
         o = {k: v.cpu().numpy() for k, v in out.items()}
-        ref, rc = oracle.wbc_solve_batch(inp, oracle.default_cfg(mode), oracle.default_wbc_params(mode), threads=16)
+        ref, rc = oracle.wbc_solve_batch(inp, oracle.default_cfg(mode), oracle.default_wbc_params(mode, **kw), threads=16)
         errs, over = {}, np.zeros(N, dtype=bool)
         for key, width in (("x", 30), ("qdd", 12), ("tau", 12), ("v", 40), ("level_res", 5)):
             r = ref[key][:, :width] if key == "v" else ref[key]
@@ -40,7 +43,7 @@ for mode in ("reference", "paper"):
         worst = max(errs.values())
         ok = worst <= 1e-6 and nst == 0 and flag_diff == 0 and rc == 0
         bad += not ok
-        print(f"{mode:9s} {kind:6s} N={N} rc={rc} worst={worst:.2e} {errs} gpu_status!=0:{nst} oracle_status!=0:{nref} "
+        print(f"{mode:9s}{'/C5' if kw else ''} {kind:6s} N={N} rc={rc} worst={worst:.2e} {errs} gpu_status!=0:{nst} oracle_status!=0:{nref} "
               f"flag_diff:{flag_diff} over_1e-6:{int(over.sum())} of {N} (indices {np.flatnonzero(over)[:8].tolist()}) "
               f"x_err/|x|_inf:{xrel:.2e} iters_max:{int(o['iters'].max())} {'OK' if ok else 'FAIL'}", flush=True)
 print("ALL OK" if bad == 0 else f"{bad} case(s) FAILED")
