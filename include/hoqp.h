@@ -47,7 +47,7 @@ extern "C" {
 #define HOQP_STATUS_INFEASIBLE_START 0x02 /* a prior (hard) row was violated when a level started */
 #define HOQP_STATUS_WORKSPACE 0x04	 /* working set outgrew the LDS workspace */
 #define HOQP_STATUS_NONFINITE 0x08	 /* NaN/Inf in the inputs or the solution */
-#define HOQP_STATUS_UNSUPPORTED 0x10	 /* Q3 pairing with >= 3 inequality levels */
+#define HOQP_STATUS_UNSUPPORTED 0x10	 /* (unused since Q3 is reproduced for any number of inequality levels) */
 
 typedef struct hoqp_handle hoqp_handle;
 

@@ -373,7 +373,7 @@ static int fill_args(hoqp_handle *h, const hoqp_task_batch *t, const hoqp_result
 	a->batch = t->batch;
 	a->n = t->n;
 	a->L = t->num_levels;
-	int P = 0, mm = 0, nineq = 0;
+	int P = 0, mm = 0;
 	for (int k = 0; k < t->num_levels; ++k) {
 		if (t->m[k] < 0 || t->m[k] > HOQP_MAX_EQ_ROWS || t->p[k] < 0)
 			return fail(h, -1, "level row counts out of range");
@@ -386,7 +386,6 @@ static int fill_args(hoqp_handle *h, const hoqp_task_batch *t, const hoqp_result
 		a->D[k] = t->D[k];
 		a->f[k] = t->f[k];
 		P += t->p[k];
-		nineq += t->p[k] > 0;
 		mm = std::max(mm, t->m[k]);
 	}
 	if (P > HOQP_MAX_INEQ_ROWS)
@@ -398,8 +397,6 @@ static int fill_args(hoqp_handle *h, const hoqp_task_batch *t, const hoqp_result
 	a->p_inst = t->p_inst;
 	a->gate_prior = (h->cfg.semantics & HOQP_Q2_GATE_PRIOR_INEQ) ? 1 : 0;
 	a->slack_quirk = (h->cfg.semantics & HOQP_Q3_SLACK_ORDER) ? 1 : 0;
-	if (a->slack_quirk && nineq >= 3)
-		return fail(h, -4, "Q3 slack pairing with >= 3 inequality levels is not supported");
 	a->max_iter = h->cfg.max_iter > 0 ? h->cfg.max_iter : 200;
 	a->eps = h->cfg.eps;
 	a->out = *out;

@@ -1073,6 +1073,7 @@ struct LevelState {
 	int P;	   // live stored inequality rows
 	int Pout;  // inequality rows emitted so far (offset of this level's slacks in out.v)
 	int status;
+	double vrow;  // lane r: optimal slack v* of stored inequality row r
 	unsigned long long t_last;
 };
 
@@ -1536,8 +1537,34 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 		HOQP_STAMP(4);
 	}
 
+	// Q3 (ho_qp_problem.cpp:83-101, 224-225): the reference stacks the prior rows newest level
+	// first but their optimal slacks oldest level first and adds the two element-wise.  Stored
+	// row r (oldest first here) of a level block [off, off + pj) sits at position
+	// P - off - pj + (r - off) of the reference's row stack and is therefore relaxed by the slack
+	// of stored row number <that position>.  delta = that slack - the row's own.
+	const bool q3 = a.slack_quirk && consider && P > 0;
+	auto q3_delta = [&]() {
+		int off = 0, myoff = 0, myp = 0;
+		for (int j = 0; j < k; ++j) {
+			const int pj = uni(a.p_inst ? a.p_inst[(size_t)inst * a.L + j] : a.p[j]);
+			if (lane >= off && lane < off + pj) {
+				myoff = off;
+				myp = pj;
+			}
+			off += pj;
+		}
+		const int src = P - myoff - myp + (lane - myoff);
+		const double vs = __shfl(st.vrow, (lane < P) ? src : lane);
+		return (lane < P) ? vs - st.vrow : 0.0;
+	};
 	if (consider) {
 		// ---- 4b. primal active set on the piecewise quadratic ----
+		if (q3) {
+			const double dq = q3_delta();
+			if (lane < P)
+				l.g[lane] += dq;
+			wave_sync();
+		}
 		if (lane < Pn)
 			l.s[lane] = -l.g[lane];
 		if (lane < mB)
@@ -1776,12 +1803,14 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 		// one row per lane: x += (Z y), g -= (G y) with the slack bookkeeping of this level's rows
 		if (lane < n)
 			l.x[lane] += l.S[lane];
+		const double dq = q3 ? q3_delta() : 0.0;  // stored g goes back to each row's own slack
 		if (lane < Pg) {
-			double gi = l.g[lane] - l.S[n + lane];
+			double gi = l.g[lane] - l.S[n + lane] - dq;
 			if (lane >= P) {
 				// v* = (D x - f)_+ ; the row becomes hard with rhs f + v* - D x
+				st.vrow = fmax(0.0, -gi);
 				if (a.out.v)
-					a.out.v[(size_t)inst * a.Ptot + st.Pout + (lane - P)] = fmax(0.0, -gi);
+					a.out.v[(size_t)inst * a.Ptot + st.Pout + (lane - P)] = st.vrow;
 				gi = fmax(gi, 0.0);
 			}
 			l.g[lane] = gi;
@@ -1831,6 +1860,7 @@ __global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
 	st.P = 0;
 	st.Pout = 0;
 	st.status = 0;
+	st.vrow = 0.0;
 	st.t_last = __builtin_amdgcn_s_memtime();
 	const int n = st.n, ld = a.ld;
 	// InitPrevProblemValuesToDefault, ho_qp_problem.cpp:119-128:  Z = I, x = 0

@@ -136,6 +136,8 @@ def _random_hierarchy(rng, B, n, spec):
     (10, [(0, 5), (4, 0), (3, 4), (6, 0)]),         # ineq first, mixed level, two ineq levels
     (6, [(6, 0), (2, 3)]),                          # K6: full-rank first level -> empty null space
     (12, [(4, 6), (5, 0), (0, 0), (8, 0)]),         # empty level
+    (14, [(0, 4), (2, 5), (0, 3), (3, 4), (9, 0)]), # four ineq levels: Q3 slack pairing (reference mode)
+    (9, [(0, 6), (0, 2), (2, 7), (7, 0)]),          # three ineq levels of different sizes
 ])
 def test_generic_tasks(solver_factory, oracle, mode, n, spec):
     import torch
@@ -151,6 +153,7 @@ def test_generic_tasks(solver_factory, oracle, mode, n, spec):
     cfg = oracle.default_cfg(mode)
     L = len(spec)
     full_rank_end = sum(m for m, _ in spec) >= n
+    compared = 0
     for i in range(B):
         r = oracle.solve_tasks([{k: v[i] for k, v in t.items()} for t in tasks], n, cfg)
         if r["rc"] != 0:
@@ -169,6 +172,56 @@ def test_generic_tasks(solver_factory, oracle, mode, n, spec):
                 _close(o["level_res"][i, k], res_ref, f"level_res {k} inst {i}")
         if full_rank_end:
             _close(o["x"][i], r["x_levels"][L - 1], f"x inst {i}")
+        compared += 1
+    assert compared >= B // 4, compared
+
+
+@pytest.mark.parametrize("n,spec,shift", [
+    (6, [(0, 6), (0, 3), (0, 5), (6, 0)], 0.0),
+    (4, [(0, 4), (0, 2), (0, 3), (4, 0)], -0.2),
+    (3, [(0, 4), (0, 2), (0, 3), (0, 3), (3, 0)], -0.3),
+])
+def test_q3_slack_pairing(solver_factory, oracle, n, spec, shift):
+    """Three and four inequality levels with non-zero slacks under reference semantics: the prior
+    rows are relaxed by the mis-paired slacks of ho_qp_problem.cpp:83-101, 224-225 (Q3).  Instances
+    whose mis-paired prior rows are infeasible have no defined reference result (the reference's
+    QP solve fails there) and are skipped; among the others there must be instances where the
+    quirk changes the answer, and the HIP path must follow the quirk there."""
+    import torch
+
+    rng = np.random.default_rng(5)
+    B = 512
+    tasks = _random_hierarchy(rng, B, n, spec)
+    for t in tasks:
+        if "f" in t:
+            t["f"] += shift - 0.5
+    s = solver_factory("reference")
+    out = s.solve_tasks([{k: torch.as_tensor(v).contiguous().cuda() for k, v in t.items()} for t in tasks], n)
+    s.synchronize()
+    o = {k: v.cpu().numpy() for k, v in out.items()}
+    cfg = oracle.default_cfg("reference")
+    plain = oracle.default_cfg("reference")
+    plain.slack_order_quirk = 0
+    L = len(spec)
+    compared = sensitive = 0
+    for i in range(B):
+        ti = [{k: v[i] for k, v in t.items()} for t in tasks]
+        r = oracle.solve_tasks(ti, n, cfg)
+        if r["rc"] != 0:
+            continue
+        assert o["status"][i] == 0, (i, o["status"][i])
+        voff = 0
+        for k, (m, p) in enumerate(spec):
+            if p:
+                _close(o["v"][i, voff:voff + p], r["v_levels"][k], f"v level {k} inst {i}")
+                voff += p
+        _close(o["x"][i], r["x_levels"][L - 1], f"x inst {i}")
+        compared += 1
+        r2 = oracle.solve_tasks(ti, n, plain)
+        d = [np.abs(r2["x_levels"][-1] - r["x_levels"][-1]).max()]
+        d += [np.abs(a - b).max() for a, b in zip(r["v_levels"], r2["v_levels"]) if len(a)]
+        sensitive += r2["rc"] != 0 or max(d) > 1e-6
+    assert compared >= B // 8 and sensitive >= 8, (compared, sensitive)
 
 
 def _lowrank(rng, B, m, n, r):
