@@ -1288,6 +1288,11 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 	// itself; with full column rank that is the whole answer (unique y, empty null space).
 	// A rank-deficient tall level falls back to the general path (second pass of the loop).
 	bool tall = m > nz && nz > 0;
+	// A level without inequality rows of its own that has to respect stored rows (paper
+	// semantics) first tries its unconstrained optimum: if no stored row objects, that is the
+	// answer and the active-set loop is skipped.
+	const bool tryfast = consider && p == 0;
+	bool have_y0 = false;
 	// ---- 1. project the task into the current null space (ConstructH/C/D/FVector,
 	//         ho_qp_problem.cpp:180-285, in factored form) ----
 	auto project = [&](bool doA, bool doD) {
@@ -1413,7 +1418,8 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 				}
 				if (lane < nz)
 					l.r0[lane] = cl;
-			} else {
+			}
+			if (!consider || tryfast) {
 				// ---- 4t. T z = c1, y = Pi z (+ eps term: z <- z - eps (T'T)^-1 z) ----
 				const bool act = lane < nz;
 				double inv = fast_rcp(l.rdiag[act ? lane : 0]);
@@ -1432,6 +1438,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 				wave_sync();
 				yi = sel(act, l.tmp[l.colpos[act ? lane : 0] & (kWave - 1)]);
 				level_res2 = res_const;
+				have_y0 = true;
 			}
 			wave_sync();
 			HOQP_STAMP(3);
@@ -1502,10 +1509,12 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 				if (s == 0 && hasc)
 					l.r0[j] = rq;
 			}
-		} else if (rank > 0) {
+		}
+		if ((!consider || tryfast) && rank > 0) {
 			// ---- 4a. unconstrained level: y1 = argmin |R' y1 - r| (+ eps term), y2 = 0 ----
 			if (nunp > XROWS) {
-				st.status |= HOQP_STATUS_WORKSPACE;
+				if (!consider)
+					st.status |= HOQP_STATUS_WORKSPACE;
 			} else {
 				if (nunp > 0) {
 #pragma unroll
@@ -1524,8 +1533,9 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 				}
 				wave_sync();
 				yi = ls_solve_reg(0, rank, 0, m, nunp, a.eps, ld, &level_res2, l);
+				have_y0 = true;
 			}
-		} else {
+		} else if (!consider) {
 			const double r = sel(lane < m, l.rhs[lane]);
 			level_res2 = wave_sum(r * r);
 		}
@@ -1557,14 +1567,30 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 		const double vs = __shfl(st.vrow, (lane < P) ? src : lane);
 		return (lane < P) ? vs - st.vrow : 0.0;
 	};
-	if (consider) {
-		// ---- 4b. primal active set on the piecewise quadratic ----
-		if (q3) {
-			const double dq = q3_delta();
-			if (lane < P)
-				l.g[lane] += dq;
-			wave_sync();
+	if (q3) {
+		const double dq = q3_delta();
+		if (lane < P)
+			l.g[lane] += dq;
+		wave_sync();
+	}
+	bool skip_qp = false;
+	if (tryfast && have_y0) {
+		// does any stored row object to the unconstrained optimum?
+		wave_sync();
+		l.tmp[lane] = (lane < nz) ? yi : 0.0;
+		wave_sync();
+		rows_dot<4>(l.G, P, ld, nz, l.tmp, l.c);
+		wave_sync();
+		const double gl = sel(lane < P, l.g[lane < P ? lane : 0]);
+		const double cl = sel(lane < P, l.c[lane < P ? lane : 0]);
+		skip_qp = __ballot(lane < P && cl - gl > 1e-11 * (1.0 + fabs(gl))) == 0ull;
+		if (!skip_qp) {
+			yi = 0.0;
+			level_res2 = 0.0;
 		}
+	}
+	if (consider && !skip_qp) {
+		// ---- 4b. primal active set on the piecewise quadratic ----
 		if (lane < Pn)
 			l.s[lane] = -l.g[lane];
 		if (lane < mB)
