@@ -66,7 +66,9 @@ typedef struct {
 void hoqp_default_config(hoqp_config *cfg);
 
 /* Replaces: HoQpController::HoQpController (ho_qp_controller.cpp:5).  One handle per host
- * thread and GPU; handles share no mutable state. */
+ * thread and GPU; handles share no mutable state.  A handle owns the task workspace of
+ * hoqp_solve_wbc_batched, so calls on ONE handle must be issued to one stream at a time
+ * (use a handle per stream to overlap launches). */
 int hoqp_create(const hoqp_config *cfg, hoqp_handle **out);
 int hoqp_destroy(hoqp_handle *h);
 const char *hoqp_last_error_string(const hoqp_handle *h);
