@@ -491,9 +491,9 @@ static int launch_solve(hoqp_handle *h, SolveArgs &a, hipStream_t s)
 	size_t lds = (size_t)lds_offsets(a).total;
 	if ((int)lds > h->max_lds)
 		return fail(h, -5, "LDS workspace " + std::to_string(lds) + " B exceeds the device limit");
+	auto kern = a.gate_prior ? hoqp_solve_kernel<true> : hoqp_solve_kernel<false>;
 	if (lds > 48 * 1024)
-		HIP_OK(h, hipFuncSetAttribute((const void *)hoqp_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-					       (int)lds));
+		HIP_OK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 	if (a.batch == 0)
 		return 0;
 	hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -502,7 +502,7 @@ static int launch_solve(hoqp_handle *h, SolveArgs &a, hipStream_t s)
 		HIP_OK(h, hipEventCreate(&e1));
 		HIP_OK(h, hipEventRecord(e0, s));
 	}
-	hipLaunchKernelGGL(hoqp_solve_kernel, dim3(a.batch), dim3(kWave), lds, s, a);
+	hipLaunchKernelGGL(kern, dim3(a.batch), dim3(kWave), lds, s, a);
 	HIP_OK(h, hipGetLastError());
 	if (e0) {
 		HIP_OK(h, hipEventRecord(e1, s));

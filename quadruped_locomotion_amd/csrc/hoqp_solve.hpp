@@ -47,7 +47,7 @@ struct SolveArgs {
 
 // byte offsets of the LDS arrays (shared by host sizing and device addressing)
 struct LdsOff {
-	int Z, x, G, g, s, c, TV, S, BL, r0, rho, a0, tau, rdiag, rhs, X, tmp, dump, pivlane, W, xlane, colpos, vlist, total;
+	int Z, x, G, g, vs, s, c, TV, S, BL, r0, rho, a0, tau, rdiag, rhs, X, tmp, dump, pivlane, W, xlane, colpos, vlist, total;
 };
 
 __host__ __device__ inline LdsOff lds_offsets(const SolveArgs &a)
@@ -65,6 +65,7 @@ __host__ __device__ inline LdsOff lds_offsets(const SolveArgs &a)
 	o.x = take(8 * NR);
 	o.G = take(8 * (P ? P : 1) * ld);
 	o.g = take(8 * (P + 1));
+	o.vs = take(8 * (P + 1));  // optimal slack v* of every stored inequality row (Q3)
 	o.s = take(8 * (P + 1));
 	o.c = take(8 * (P + 1));
 	o.TV = take(8 * tv);
@@ -90,7 +91,7 @@ __host__ __device__ inline LdsOff lds_offsets(const SolveArgs &a)
 
 #ifdef __HIP_DEVICE_COMPILE__
 struct Lds {
-	ldsd *Z, *x, *G, *g, *s, *c, *TV, *S, *BL, *r0, *rho, *a0, *tau, *rdiag, *rhs, *X, *tmp, *dump;
+	ldsd *Z, *x, *G, *g, *vs, *s, *c, *TV, *S, *BL, *r0, *rho, *a0, *tau, *rdiag, *rhs, *X, *tmp, *dump;
 	ldsi *pivlane, *W, *xlane, *colpos, *vlist;
 };
 
@@ -102,6 +103,7 @@ __device__ __forceinline__ Lds lds_bind(const SolveArgs &a, HOQP_LDS char *base)
 	l.x = (ldsd *)(base + o.x);
 	l.G = (ldsd *)(base + o.G);
 	l.g = (ldsd *)(base + o.g);
+	l.vs = (ldsd *)(base + o.vs);
 	l.s = (ldsd *)(base + o.s);
 	l.c = (ldsd *)(base + o.c);
 	l.TV = (ldsd *)(base + o.TV);
@@ -1073,7 +1075,6 @@ struct LevelState {
 	int P;	   // live stored inequality rows
 	int Pout;  // inequality rows emitted so far (offset of this level's slacks in out.v)
 	int status;
-	double vrow;  // lane r: optimal slack v* of stored inequality row r
 	unsigned long long t_last;
 };
 
@@ -1264,6 +1265,10 @@ __device__ __forceinline__ void level_update_t(const Lds &l, int n, int Pg, int 
 // ---------------------------------------------------------------------------
 // one priority level (HoQpProblem constructor pipeline, ho_qp_problem.cpp:11-25)
 // ---------------------------------------------------------------------------
+// GATE: Q2 of the reference (levels without inequalities of their own ignore the stored rows,
+// ho_qp_problem.cpp:297-298) as a compile-time switch: the gated kernel carries none of the code
+// that only ungated hierarchies reach.
+template <bool GATE>
 __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, LevelState &st, int inst, int k, int m, int p)
 {
 	const int lane = lane_id(), s = lane & 3, c = lane >> 2;
@@ -1273,7 +1278,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 	m = uni(m);
 	p = uni(p);
 	const int Pn = P + p;
-	const bool consider = (nz > 0) && (a.gate_prior ? (p > 0) : (p > 0 || P > 0));
+	const bool consider = (nz > 0) && (GATE ? (p > 0) : (p > 0 || P > 0));
 	// stored rows are still needed by a later level?  (else they are neither rotated nor kept)
 	const bool keep_rows = k < a.last_ineq_use;
 	const int Pg = (consider || keep_rows) ? Pn : 0;  // rows that take part in rotation / update
@@ -1291,7 +1296,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 	// A level without inequality rows of its own that has to respect stored rows (paper
 	// semantics) first tries its unconstrained optimum: if no stored row objects, that is the
 	// answer and the active-set loop is skipped.
-	const bool tryfast = consider && p == 0;
+	const bool tryfast = !GATE && consider && p == 0;
 	bool have_y0 = false;
 	// ---- 1. project the task into the current null space (ConstructH/C/D/FVector,
 	//         ho_qp_problem.cpp:180-285, in factored form) ----
@@ -1564,8 +1569,9 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 			off += pj;
 		}
 		const int src = P - myoff - myp + (lane - myoff);
-		const double vs = __shfl(st.vrow, (lane < P) ? src : lane);
-		return (lane < P) ? vs - st.vrow : 0.0;
+		const bool on = lane < P;
+		const double vsrc = l.vs[on ? src : 0], vown = l.vs[on ? lane : 0];
+		return on ? vsrc - vown : 0.0;
 	};
 	if (q3) {
 		const double dq = q3_delta();
@@ -1834,9 +1840,10 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 			double gi = l.g[lane] - l.S[n + lane] - dq;
 			if (lane >= P) {
 				// v* = (D x - f)_+ ; the row becomes hard with rhs f + v* - D x
-				st.vrow = fmax(0.0, -gi);
+				const double vopt = fmax(0.0, -gi);
+				l.vs[lane] = vopt;
 				if (a.out.v)
-					a.out.v[(size_t)inst * a.Ptot + st.Pout + (lane - P)] = st.vrow;
+					a.out.v[(size_t)inst * a.Ptot + st.Pout + (lane - P)] = vopt;
 				gi = fmax(gi, 0.0);
 			}
 			l.g[lane] = gi;
@@ -1871,6 +1878,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 
 #endif  // __HIP_DEVICE_COMPILE__
 
+template <bool GATE>
 __global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
 {
 #ifdef __HIP_DEVICE_COMPILE__
@@ -1886,7 +1894,6 @@ __global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
 	st.P = 0;
 	st.Pout = 0;
 	st.status = 0;
-	st.vrow = 0.0;
 	st.t_last = __builtin_amdgcn_s_memtime();
 	const int n = st.n, ld = a.ld;
 	// InitPrevProblemValuesToDefault, ho_qp_problem.cpp:119-128:  Z = I, x = 0
@@ -1905,7 +1912,7 @@ __global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
 	for (int k = 0; k < a.L; ++k) {
 		int m = uni(a.m_inst ? a.m_inst[(size_t)inst * a.L + k] : a.m[k]);
 		int p = uni(a.p_inst ? a.p_inst[(size_t)inst * a.L + k] : a.p[k]);
-		solve_level(a, l, st, inst, k, m, p);
+		solve_level<GATE>(a, l, st, inst, k, m, p);
 	}
 
 	// ---- final x and the CheckSolutionValid flags (helper_functions.hpp:63-91) ----
