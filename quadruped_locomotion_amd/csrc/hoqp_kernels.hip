@@ -404,6 +404,7 @@ static int fill_args(hoqp_handle *h, const hoqp_task_batch *t, const hoqp_result
 	a->mmax = mm;
 	// which levels look at stored inequality rows, and does any of them also carry equality rows?
 	a->use_bl = 0;
+	a->any_hard = 0;
 	a->last_ineq_use = -1;
 	{
 		int seen = 0;
@@ -411,6 +412,8 @@ static int fill_args(hoqp_handle *h, const hoqp_task_batch *t, const hoqp_result
 			const bool looks = a->gate_prior ? (t->p[k] > 0) : (t->p[k] > 0 || seen > 0);
 			if (looks) {
 				a->last_ineq_use = k;
+				if (seen > 0)
+					a->any_hard = 1;
 				if (t->m[k] > 0)
 					a->use_bl = 1;
 			}
@@ -491,7 +494,10 @@ static int launch_solve(hoqp_handle *h, SolveArgs &a, hipStream_t s)
 	size_t lds = (size_t)lds_offsets(a).total;
 	if ((int)lds > h->max_lds)
 		return fail(h, -5, "LDS workspace " + std::to_string(lds) + " B exceeds the device limit");
-	auto kern = a.gate_prior ? hoqp_solve_kernel<true> : hoqp_solve_kernel<false>;
+	// three instantiations: no level looks at rows stored by an earlier one (the WBC hierarchy under
+	// reference semantics) / gated / ungated
+	auto kern = !a.any_hard ? hoqp_solve_kernel<true, false>
+				: (a.gate_prior ? hoqp_solve_kernel<true, true> : hoqp_solve_kernel<false, true>);
 	if (lds > 48 * 1024)
 		HIP_OK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 	if (a.batch == 0)

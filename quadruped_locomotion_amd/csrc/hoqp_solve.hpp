@@ -41,6 +41,7 @@ struct SolveArgs {
 	int mmax;  // max_k m[k] (<= 32)
 	int ld;	   // odd leading dimension >= n of Z, G, BL, X
 	int use_bl;	   // some level needs its equality rows inside the active-set loop
+	int any_hard;	   // some level looks at rows stored by an earlier level
 	int last_ineq_use; // last level that looks at stored inequality rows (rows are dropped after it)
 	unsigned long long *dbg;  // HOQP_PROFILE builds only: [batch][16] cycle stamps per section
 };
@@ -1094,9 +1095,11 @@ __device__ __forceinline__ int unp_index(bool unp, int &base)
 //   [ G_W' | B0' | G_V' ]  (w + m + |V| <= 64 columns, rows of V listed in l.vlist).
 // Returns p_i in lane i; *k1_out = rank of the working set (reflectors [0,k1) stay in TV).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ double eqp_step(const SolveArgs &a, const Lds &l, LevelState &st, int nz, int rank, int m, int w,
+template <bool HARD>
+__device__ __forceinline__ double eqp_step(const SolveArgs &a, const Lds &l, LevelState &st, int nz, int rank, int m, int w_in,
 				  int nV, int *k1_out, bool *overflow)
 {
+	const int w = HARD ? w_in : 0;  // no stored hard rows: the working set is always empty
 	const int lane = lane_id(), s = lane & 3, c = lane >> 2;
 	const int ld = a.ld;
 	const int nb = m + nV;
@@ -1145,7 +1148,7 @@ __device__ __forceinline__ double eqp_step(const SolveArgs &a, const Lds &l, Lev
 		l.colpos[lane] = -1;
 	}
 	wave_sync();
-	const int k1 = uni(panel_factor(x, pos, nslot, 0, w, nz, 0, 1e-12, l));
+	const int k1 = HARD ? uni(panel_factor(x, pos, nslot, 0, w, nz, 0, 1e-12, l)) : 0;
 	HOQP_STAMP(8);
 	const int k2 = uni(panel_factor(x, pos, nslot, w, ncol, nz, k1, 1e-11, l));
 	HOQP_STAMP(9);
@@ -1268,12 +1271,15 @@ __device__ __forceinline__ void level_update_t(const Lds &l, int n, int Pg, int 
 // GATE: Q2 of the reference (levels without inequalities of their own ignore the stored rows,
 // ho_qp_problem.cpp:297-298) as a compile-time switch: the gated kernel carries none of the code
 // that only ungated hierarchies reach.
-template <bool GATE>
+// HARD: some level of the hierarchy looks at rows stored by an earlier level (false for a single
+// inequality level under GATE, i.e. the reference's WBC hierarchy: no hard rows, no working set,
+// no phase 1, no multipliers -- all of that code is compiled out).
+template <bool GATE, bool HARD>
 __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, LevelState &st, int inst, int k, int m, int p)
 {
 	const int lane = lane_id(), s = lane & 3, c = lane >> 2;
 	const int n = uni(st.n), ld = a.ld;
-	const int nz = uni(st.nz), P = uni(st.P);
+	const int nz = uni(st.nz), P = HARD ? uni(st.P) : 0;
 	const int nstore = a.n;
 	m = uni(m);
 	p = uni(p);
@@ -1557,7 +1563,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 	// row r (oldest first here) of a level block [off, off + pj) sits at position
 	// P - off - pj + (r - off) of the reference's row stack and is therefore relaxed by the slack
 	// of stored row number <that position>.  delta = that slack - the row's own.
-	const bool q3 = a.slack_quirk && consider && P > 0;
+	const bool q3 = HARD && a.slack_quirk && consider && P > 0;
 	auto q3_delta = [&]() {
 		int off = 0, myoff = 0, myp = 0;
 		for (int j = 0; j < k; ++j) {
@@ -1610,8 +1616,8 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 		// levels without inequalities ignore the prior rows, ho_qp_problem.cpp:325-329): the same
 		// loop with the prior rows as the only, soft, rows finds a feasible y; the main phase
 		// then starts there.
-		bool need_p1;
-		{
+		bool need_p1 = false;
+		if (HARD) {
 			int bad = 0;
 			if (lane < P)
 				bad = l.s[lane] > 1e-9 * (1.0 + fabs(l.g[lane]));
@@ -1669,7 +1675,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 			HOQP_STAMP(5);
 			double pi = 0.0;
 			if (!(prev_full && vmask == prev_vmask)) {
-				pi = eqp_step(a, l, st, nz, rank, mB, w, nV, &k1, &overflow);
+				pi = eqp_step<HARD>(a, l, st, nz, rank, mB, w, nV, &k1, &overflow);
 				if (overflow) {
 					st.status |= HOQP_STATUS_WORKSPACE;
 					break;
@@ -1680,7 +1686,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 			const double pn = wave_max(fabs(pi));
 			const double yn = wave_max(fabs(yi));
 			if (!(pn > 1e-10 * (1.0 + yn))) {
-				if (w == 0) {
+				if (!HARD || w == 0) {
 					done = true;
 					break;
 				}
@@ -1736,14 +1742,17 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 			const double a0 = sel(lane < mB, l.a0[lane < mB ? lane : 0]);
 			const double q0 = wave_sum(a0 * rj), q1 = wave_sum(a0 * a0);
 			// ratio test on hard rows outside the working set
-			const bool isHard = lane < P && ((hardmask >> lane) & 1ull) && !((wmask >> lane) & 1ull);
-			double ah = 1e300;
-			if (isHard && ci > 1e-12 * pn)
-				ah = fmax(0.0, -si / ci);
-			int blk;
-			double t_hard = wave_argmin(ah, lane, &blk);
-			if (!(t_hard < 1e299))
-				blk = -1;
+			int blk = -1;
+			double t_hard = 1e300;
+			if (HARD) {
+				const bool isHard = lane < P && ((hardmask >> lane) & 1ull) && !((wmask >> lane) & 1ull);
+				double ah = 1e300;
+				if (isHard && ci > 1e-12 * pn)
+					ah = fmax(0.0, -si / ci);
+				t_hard = wave_argmin(ah, lane, &blk);
+				if (!(t_hard < 1e299))
+					blk = -1;
+			}
 			// exact line search on the piecewise quadratic along p
 			double tb = 1e300;
 			if (isSoft && ci != 0.0 && ((si > tolv && ci < 0.0) || (si <= tolv && ci > 0.0))) {
@@ -1789,7 +1798,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 				l.s[lane] = fma(t, ci, si);
 			if (lane < mB)
 				l.rho[lane] = fma(t, a0, rj);
-			if (t_hard <= t_star && blk >= 0) {
+			if (HARD && t_hard <= t_star && blk >= 0) {
 				if (w < NR) {
 					if (lane == 0)
 						l.W[w] = blk;
@@ -1878,7 +1887,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 
 #endif  // __HIP_DEVICE_COMPILE__
 
-template <bool GATE>
+template <bool GATE, bool HARD>
 __global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
 {
 #ifdef __HIP_DEVICE_COMPILE__
@@ -1912,7 +1921,7 @@ __global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
 	for (int k = 0; k < a.L; ++k) {
 		int m = uni(a.m_inst ? a.m_inst[(size_t)inst * a.L + k] : a.m[k]);
 		int p = uni(a.p_inst ? a.p_inst[(size_t)inst * a.L + k] : a.p[k]);
-		solve_level<GATE>(a, l, st, inst, k, m, p);
+		solve_level<GATE, HARD>(a, l, st, inst, k, m, p);
 	}
 
 	// ---- final x and the CheckSolutionValid flags (helper_functions.hpp:63-91) ----
