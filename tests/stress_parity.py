@@ -18,7 +18,10 @@ SEED0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 bad = 0
 C5 = dict(mu=0.2, tau_max=40.0, tau_min=-40.0)   # friction / torque rows go active
 for mode, kw in (("reference", {}), ("paper", {}), ("paper", C5)):
-    s = hoqp.HoQpSolver(hoqp.default_config(mode, **kw))
+    gkw = dict(kw)
+    if os.environ.get("HOQP_STRESS_GPU_EPS0") and mode == "reference":
+        gkw["eps"] = 0.0   # experiment: how much of the parity comes from the eps correction on the device?
+    s = hoqp.HoQpSolver(hoqp.default_config(mode, **gkw))
     for kind, seed in (("stance", 11), ("trot", 12), ("three", 13)):
         if kw and kind != "three":
             continue
