@@ -224,6 +224,55 @@ def test_q3_slack_pairing(solver_factory, oracle, n, spec, shift):
     assert compared >= B // 8 and sensitive >= 8, (compared, sensitive)
 
 
+@pytest.mark.parametrize("mode", ["reference", "paper"])
+def test_nullspace_projector_and_lexicographic_optimality(solver_factory, oracle, mode):
+    """K11, on the HIP path's own outputs, plus the projector comparison with the
+    oracle: Z_k orthonormal; A_j Z_k = 0 for j <= k; every level is stationary on
+    x_{k-1} + range(Z_{k-1}) (no direction that keeps the higher priorities lowers its cost);
+    lower levels never change a higher level's residual; and range(Z_k) is the oracle's
+    (its FullPivLU basis is not orthonormal, so the projectors are compared, tolerance 1e-8)."""
+    import torch
+
+    rng = np.random.default_rng(21)
+    B, n = 48, 14
+    spec = [(3, 0), (4, 0), (5, 0), (2, 0)]
+    tasks = _random_hierarchy(rng, B, n, spec)
+    tasks[1]["A"][:, 3] = tasks[1]["A"][:, 0] - 2.0 * tasks[1]["A"][:, 1]      # a dependent row
+    tasks[2]["A"][:, 4] = tasks[0]["A"][:, 1] + tasks[1]["A"][:, 2]            # conflicts with higher levels
+    s = solver_factory(mode)
+    out = s.solve_tasks([{k: torch.as_tensor(v).contiguous().cuda() for k, v in t.items()} for t in tasks], n,
+                        debug=True)
+    s.synchronize()
+    o = {k: v.cpu().numpy() for k, v in out.items()}
+    cfg = oracle.default_cfg(mode)
+    cfg.zero_kernel_col = 0
+    assert np.all(o["status"] == 0)
+    for i in range(B):
+        r = oracle.solve_tasks([{k: v[i] for k, v in t.items()} for t in tasks], n, cfg)
+        assert r["rc"] == 0
+        Zprev, xprev = np.eye(n), np.zeros(n)
+        for k, (m, _) in enumerate(spec):
+            A, b = tasks[k]["A"][i], tasks[k]["b"][i]
+            nz = int(o["nz_levels"][i, k])
+            Z, x = o["Z_levels"][i, k][:, :nz], o["x_levels"][i, k]
+            assert nz == r["nz_levels"][k]
+            assert np.abs(Z.T @ Z - np.eye(nz)).max() < 1e-12
+            for j in range(k + 1):
+                assert np.abs(tasks[j]["A"][i] @ Z).max() < 1e-10
+            # stationarity on the affine set the level may move in, and x_k stays on it
+            assert np.abs(Zprev.T @ A.T @ (A @ x - b)).max() < 1e-9
+            d = x - xprev
+            assert np.abs(d - Zprev @ (Zprev.T @ d)).max() < 1e-10
+            for j in range(k):
+                rj = np.linalg.norm(tasks[j]["A"][i] @ o["x_levels"][i, j] - tasks[j]["b"][i])
+                assert abs(np.linalg.norm(tasks[j]["A"][i] @ x - tasks[j]["b"][i]) - rj) < 1e-9
+            Zo = r["Z_levels"][k]
+            Po = Zo @ np.linalg.solve(Zo.T @ Zo, Zo.T) if Zo.shape[1] else np.zeros((n, n))
+            assert np.linalg.norm(Z @ Z.T - Po) < 1e-8
+            _close(o["level_res"][i, k], np.linalg.norm(A @ r["x_levels"][k] - b), f"level_res {k} inst {i}")
+            Zprev, xprev = Z, x
+
+
 def _lowrank(rng, B, m, n, r):
     """m rows of rank r (every row a random combination of r base rows)."""
     base = rng.normal(size=(B, r, n))
