@@ -40,6 +40,29 @@ struct WbcArgs {
 
 constexpr int kNU = 18, kNJ = 12, kNB = 6, kNX = 30;
 
+// Fill `count` consecutive doubles (one per lane and pass): every value of the block is computed
+// first (the gathers from M / J are independent and stay in flight together), then stored.  The
+// task arrays and the inputs are reached through struct members, so without the split the
+// compiler has to keep each store ahead of the next pass's loads.
+template <int COUNT, typename F>
+__device__ __forceinline__ void fill_block(double *dst, F value)
+{
+	constexpr int PASSES = (COUNT + kWave - 1) / kWave;
+	const int lane = lane_id();
+	double v[PASSES];
+#pragma unroll
+	for (int it = 0; it < PASSES; ++it) {
+		const int idx = lane + kWave * it;
+		v[it] = value(idx < COUNT ? idx : COUNT - 1);
+	}
+#pragma unroll
+	for (int it = 0; it < PASSES; ++it) {
+		const int idx = lane + kWave * it;
+		if (idx < COUNT)
+			dst[idx] = v[it];
+	}
+}
+
 __global__ void __launch_bounds__(kWave) wbc_build_kernel(const WbcArgs a)
 {
 	const int lane = lane_id();
@@ -89,15 +112,15 @@ __global__ void __launch_bounds__(kWave) wbc_build_kernel(const WbcArgs a)
 	// level 0: ConstructFloatingBaseEomTask, :351-366
 	{
 		double *A = a.A0 + (size_t)inst * kNB * kNX;
-		for (int idx = lane; idx < kNB * kNX; idx += kWave) {
+		fill_block<kNB * kNX>(A, [&](int idx) {
 			int r = idx / kNX, c = idx - r * kNX;
 			double v = 0.0;
 			if (c < kNU)
 				v = M[r * kNU + c];
 			else if (c < n)
 				v = -JC(c - kNU, r);
-			A[idx] = v;
-		}
+			return v;
+		});
 		if (lane < kNB)
 			a.b0[(size_t)inst * kNB + lane] = -h[lane];
 	}
@@ -105,7 +128,7 @@ __global__ void __launch_bounds__(kWave) wbc_build_kernel(const WbcArgs a)
 	{
 		double *D = a.D1 + (size_t)inst * 40 * kNX;
 		double *f = a.f1 + (size_t)inst * 40;
-		for (int idx = lane; idx < 40 * kNX; idx += kWave) {
+		fill_block<40 * kNX>(D, [&](int idx) {
 			int r = idx / kNX, c = idx - r * kNX;
 			double v = 0.0;
 			if (r < 2 * kNJ) {
@@ -126,8 +149,8 @@ __global__ void __launch_bounds__(kWave) wbc_build_kernel(const WbcArgs a)
 				else if (d == 1 && t >= 2)
 					v = (t == 2) ? 1.0 : -1.0;
 			}
-			D[idx] = v;
-		}
+			return v;
+		});
 		if (lane < 40) {
 			double v = 0.0;
 			if (lane < kNJ)
@@ -140,17 +163,17 @@ __global__ void __launch_bounds__(kWave) wbc_build_kernel(const WbcArgs a)
 	// level 2: ConstructNoContactMotionTask, :283-297
 	{
 		double *A = a.A2 + (size_t)inst * 12 * kNX;
-		for (int idx = lane; idx < 12 * kNX; idx += kWave) {
+		fill_block<12 * kNX>(A, [&](int idx) {
 			int r = idx / kNX, c = idx - r * kNX;
-			A[idx] = (r < 3 * nc && c < kNU) ? JC(r, c) : 0.0;
-		}
+			return (r < 3 * nc && c < kNU) ? JC(r, c) : 0.0;
+		});
 		if (lane < 12)
 			a.b2[(size_t)inst * 12 + lane] = (lane < 3 * nc) ? -Jdu[cl[lane / 3] * 3 + lane % 3] : 0.0;
 	}
 	// level 3: base pos :217-247, base rot :249-281, swing legs :186-215
 	{
 		double *A = a.A3 + (size_t)inst * 18 * kNX;
-		for (int idx = lane; idx < 18 * kNX; idx += kWave) {
+		fill_block<18 * kNX>(A, [&](int idx) {
 			int r = idx / kNX, c = idx - r * kNX;
 			double v = 0.0;
 			if (c < kNU) {
@@ -161,8 +184,8 @@ __global__ void __launch_bounds__(kWave) wbc_build_kernel(const WbcArgs a)
 				else if (r < 6 + 3 * ns)
 					v = JS(r - 6, c);
 			}
-			A[idx] = v;
-		}
+			return v;
+		});
 		if (lane < 18) {
 			double v = 0.0;
 			if (lane < 3) {
@@ -185,10 +208,10 @@ __global__ void __launch_bounds__(kWave) wbc_build_kernel(const WbcArgs a)
 	// level 4: ConstructForceMinimizationTask, :385-400
 	{
 		double *A = a.A4 + (size_t)inst * 12 * kNX;
-		for (int idx = lane; idx < 12 * kNX; idx += kWave) {
+		fill_block<12 * kNX>(A, [&](int idx) {
 			int r = idx / kNX, c = idx - r * kNX;
-			A[idx] = (r < 3 * nc && c == kNU + r) ? 1.0 : 0.0;
-		}
+			return (r < 3 * nc && c == kNU + r) ? 1.0 : 0.0;
+		});
 		if (lane < 12)
 			a.b4[(size_t)inst * 12 + lane] = 0.0;
 	}
