@@ -34,6 +34,11 @@ ALG_BYTES_PER_SOLVE = 8 * 76 * 31 + 664
 ALG_FLOPS_PER_SOLVE = 210_984
 
 
+# which BASELINE.json configuration a --contact choice restates
+WORKLOAD_LABEL = {"stance": "configs[1]", "trot": "configs[2] (trot mix)", "three": "configs[4] (swing tracking)",
+                  "crawl": "crawl gait of the reference via the command sampler"}
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -88,7 +93,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=4096, help="states per GPU per step")
     ap.add_argument("--mode", default="reference", choices=["reference", "paper"])
-    ap.add_argument("--contact", default="stance", choices=["stance", "trot", "three"])
+    ap.add_argument("--contact", default="stance", choices=["stance", "trot", "three", "crawl"],
+                    help="contact patterns: i.i.d. masks (stance / trot / three) or, for crawl, the pattern and swing "
+                         "commands of the reference's crawl gait at random phases (hoqp_gait_sample_batched)")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=512)
@@ -125,8 +132,19 @@ def main():
     if args.tau_max is not None:
         prm_kw.update(tau_max=args.tau_max, tau_min=-args.tau_max)
     solver = hoqp.HoQpSolver(hoqp.default_config(args.mode, device=local_rank, **prm_kw))
-    inp = am.make_wbc_inputs(am.sample_states(args.batch, args.seed + rank, args.contact))
+    inp = am.make_wbc_inputs(am.sample_states(args.batch, args.seed + rank,
+                                              "stance" if args.contact == "crawl" else args.contact))
     dinp = solver.to_device(inp)
+    if args.contact == "crawl":
+        # commands from the gait sampler on the device (2-, 3- and 4-contact states)
+        rng = np.random.default_rng(args.seed + rank + 77)
+        t_gait = torch.as_tensor(rng.uniform(0.0, 10.0, args.batch)).cuda()
+        v_cmd = torch.as_tensor(rng.normal(0.0, 0.1, (args.batch, 2))).cuda()
+        lc, ct = solver.gait_sample(hoqp.default_gait("crawl", fix_derivatives=1), t_gait, v_cmd,
+                                    dinp["footpos"][:, :, :2].contiguous())
+        dinp["leg_cmd"], dinp["contact"] = lc, ct
+        solver.synchronize()
+        inp["leg_cmd"], inp["contact"] = lc.cpu().numpy(), ct.cpu().numpy()
     out = solver.alloc_wbc_outputs(args.batch)
     from quadruped_locomotion_amd import parallel
 
@@ -217,8 +235,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic (own ANYmal-C-like model, seed %d)" % args.seed,
-            "config": {"workload": f"configs[1]: {args.batch} randomised {args.contact} states per GPU, "
-                                   f"5-level WBC hierarchy, {args.mode} semantics",
+            "config": {"workload": f"{WORKLOAD_LABEL[args.contact]}: {args.batch} randomised {args.contact} states "
+                                   f"per GPU, 5-level WBC hierarchy, {args.mode} semantics",
                        "batch_per_gpu": args.batch, "semantics": args.mode, "contact": args.contact,
                        "entry": "hoqp_solve_wbc_batched", "params": prm_kw or "reference defaults",
                        "gather": ("every_step" if args.gather_every_step else "after_loop")

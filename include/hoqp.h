@@ -211,6 +211,38 @@ int hoqp_wbc_poststep_batched(hoqp_handle *h, int batch, double dt, double kp, d
 			      const double *tau_ff, const double *q_j, const double *qd_j, double *q_cmd,
 			      double *qd_cmd, double *tau_cmd, void *stream);
 
+/*
+ * SURVEY 8f N3 -- the command source as a batch sampler.
+ * hoqp_gait replaces GaitSequence (include/planner/gait_sequence.hpp:3-9) plus the two constants
+ * of the swing trajectory.  kind 0 = MotionPlanner::CreateSimpleSequence, 1 = CreateCrawlSequence
+ * (motion_planner.cpp:536-575).
+ */
+#define HOQP_MAX_GAIT_STEPS 32
+typedef struct {
+	int n_steps;		  /* <= HOQP_MAX_GAIT_STEPS */
+	double duration;	  /* [s]; step_time = duration / n_steps */
+	unsigned contact_bits[4]; /* bit s of leg l = contact_schedule(l, s); legs LF, RF, LH, RH */
+	double apex_height;	  /* z_apex_height of LegPlanner::CreateZLegTrajectory (leg_planner.cpp:241) */
+	int fix_derivatives;	  /* 0: as the reference, velocity and acceleration commands evaluate the
+				   * POSITION curves (leg_planner.cpp:337-341, 358-362); 1: their derivatives */
+} hoqp_gait;
+int hoqp_default_gait(int kind, hoqp_gait *g);
+
+/* Replaces: LegPlanner::PlanLegsMotion (leg_planner.cpp:3-12) for a plan made at time 0 from the foot
+ * positions stance0 [batch][4][2] under velocity command vel_cmd [batch][2], then MotionPlanner::
+ * UpdateWalkLegCmd (motion_planner.cpp:75-81) at time[batch]: leg_cmd [batch][36] = GetStackedLeg
+ * {Pos,Vel,Acc}AtT, contact [batch][4] = GetContactPatternAtT.  Device pointers; asynchronous. */
+int hoqp_gait_sample_batched(hoqp_handle *h, const hoqp_gait *g, int batch, const double *time, const double *vel_cmd,
+			     const double *stance0, double *leg_cmd, int *contact, void *stream);
+
+/* Replaces: BasePlanner::PlanBaseStandupMotion + EvalStandup{Pos,Vel,Acc}TrajAtT
+ * (base_planner.cpp:272-317) and MotionPlanner::UpdateStandupCmd (motion_planner.cpp:53-59):
+ * base_cmd [batch][9] = (pos, vel, acc) of the ramp from curr_pose [batch][3] to the target height,
+ * contact [batch][4] = all ones (may be NULL). */
+int hoqp_standup_sample_batched(hoqp_handle *h, int batch, const double *time, double seconds_to_standup,
+				double target_height, const double *curr_pose, double *base_cmd, int *contact,
+				void *stream);
+
 /* Blocks until `stream` has drained; returns <0 if a kernel faulted. */
 int hoqp_synchronize(hoqp_handle *h, void *stream);
 

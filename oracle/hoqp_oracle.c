@@ -1097,3 +1097,106 @@ void hoqp_oracle_wbc_poststep(int N, double dt, double kp, double kd, const doub
 			tau_cmd[i] = kp * (q_cmd[i] - q_j[i]) + kd * (qd_cmd[i] - qd_j[i]) + tau_ff[i];
 	}
 }
+
+/* ---------------------------------------------------------------------------
+ * N3: the command source of the WBC as a batch sampler.
+ *
+ * Gait: LegPlanner::PlanLegsMotion (leg_planner.cpp:3-12) = GenerateStanceSequence (:105-151, a swing
+ * leg's foothold advances by vel_cmd * step_time per gait step), CreateLegMotionForLeg (:264-299,
+ * lift-off / touch-down = the schedule's 1->0 / 0->1 transitions scanned from step 1, start / end
+ * position = the stance of the step before), CreateXYLegTrajectory (:209-228, first-order hold) and
+ * CreateZLegTrajectory (:230-255, 0 -> apex -> 0 at lift-off, mid-swing, touch-down).  The z curve is
+ * Drake's PiecewisePolynomial::CubicWithContinuousSecondDerivatives on three knots (Drake absent;
+ * version unpinned, CMakeLists.txt:22): with three knots its not-a-knot end condition degenerates and
+ * Drake sets the cubic coefficients of both segments to zero, i.e. the curve is the parabola through
+ * the three points -- restated from the published implementation, parity unpinned.
+ * Evaluation: EvalLegPos/Vel/AccAtT (:302-366) with time_rel = fmod(t, duration); outside
+ * [t_liftoff, t_touchdown] everything is zero.  The reference evaluates the POSITION polynomials for
+ * velocity and acceleration as well (:337-341, :358-362); fix_derivatives = 1 evaluates the
+ * derivatives instead.  Contact pattern: GetContactPatternAtT (:55-59).
+ * leg_cmd = [pos(12); vel(12); acc(12)], legs LF, RF, LH, RH.
+ * --------------------------------------------------------------------------- */
+void hoqp_oracle_gait_sample(int N, int n_steps, double duration, const int *schedule /* [4][n_steps] */,
+			     double apex, int fix_derivatives, const double *time, const double *vel_cmd /* [N][2] */,
+			     const double *stance0 /* [N][4][2] */, double *leg_cmd /* [N][36] */, int *contact /* [N][4] */)
+{
+	const double step_time = duration / (double)n_steps;
+	for (int i = 0; i < N; ++i) {
+		const double t_rel = fmod(time[i], duration);
+		int step = (int)(t_rel / step_time);
+		if (step > n_steps - 1)
+			step = n_steps - 1;
+		for (int leg = 0; leg < 4; ++leg) {
+			const int *sch = schedule + leg * n_steps;
+			double pos[2] = {stance0[(i * 4 + leg) * 2], stance0[(i * 4 + leg) * 2 + 1]};
+			double t_lo = -1.0, t_td = -1.0, start[2] = {0, 0}, end[2] = {0, 0};
+			int last = sch[0];
+			for (int g = 1; g < n_steps; ++g) {
+				const double prev[2] = {pos[0], pos[1]};
+				if (sch[g] != 1) {
+					pos[0] += vel_cmd[i * 2] * step_time;
+					pos[1] += vel_cmd[i * 2 + 1] * step_time;
+				}
+				if (sch[g] != last) {
+					if (last == 1) {
+						t_lo = step_time * g;
+						last = 0;
+						start[0] = prev[0];
+						start[1] = prev[1];
+					} else {
+						t_td = step_time * g;
+						last = 1;
+						end[0] = prev[0];
+						end[1] = prev[1];
+					}
+				}
+			}
+			double p[3] = {0, 0, 0}, v[3] = {0, 0, 0}, a[3] = {0, 0, 0};
+			if (!(t_rel < t_lo || t_rel > t_td)) {
+				const double T = t_td - t_lo, half = 0.5 * fabs(T);
+				const double w = (t_rel - t_lo) / T;
+				const double u = (t_rel - (t_lo + half)) / half;
+				p[0] = start[0] + w * (end[0] - start[0]);
+				p[1] = start[1] + w * (end[1] - start[1]);
+				p[2] = apex * (1.0 - u * u);
+				if (fix_derivatives) {
+					v[0] = (end[0] - start[0]) / T;
+					v[1] = (end[1] - start[1]) / T;
+					v[2] = -2.0 * apex * u / half;
+					a[2] = -2.0 * apex / (half * half);
+				} else {
+					for (int d = 0; d < 3; ++d)
+						v[d] = a[d] = p[d];
+				}
+			}
+			for (int d = 0; d < 3; ++d) {
+				leg_cmd[i * 36 + leg * 3 + d] = p[d];
+				leg_cmd[i * 36 + 12 + leg * 3 + d] = v[d];
+				leg_cmd[i * 36 + 24 + leg * 3 + d] = a[d];
+			}
+			contact[i * 4 + leg] = sch[step];
+		}
+	}
+}
+
+/* Stand-up ramp: BasePlanner::PlanBaseStandupMotion / EvalStandup{Pos,Vel,Acc}TrajAtT
+ * (base_planner.cpp:272-317): first-order hold from the current pose to (x, y, target height) over
+ * `seconds`, held afterwards; velocity = the constant slope, acceleration = 0, both zero after the ramp;
+ * all legs in contact (motion_planner.cpp:53-59).  base_cmd = [pos(3); vel(3); acc(3)]. */
+void hoqp_oracle_standup_sample(int N, double seconds, double target_height, const double *time,
+				const double *curr_pose /* [N][3] */, double *base_cmd /* [N][9] */, int *contact)
+{
+	for (int i = 0; i < N; ++i) {
+		const double *c = curr_pose + i * 3;
+		const double tgt[3] = {c[0], c[1], target_height};
+		const double t = time[i];
+		for (int d = 0; d < 3; ++d) {
+			const double slope = (tgt[d] - c[d]) / seconds;
+			base_cmd[i * 9 + d] = (t > seconds) ? tgt[d] : c[d] + slope * t;
+			base_cmd[i * 9 + 3 + d] = (t > seconds) ? 0.0 : slope;
+			base_cmd[i * 9 + 6 + d] = 0.0;
+		}
+		for (int leg = 0; leg < 4; ++leg)
+			contact[i * 4 + leg] = 1;
+	}
+}

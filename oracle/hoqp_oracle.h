@@ -7,6 +7,13 @@
 
 #ifdef __cplusplus
 extern "C" {
+/* N3: command / gait sampler (leg_planner.cpp, base_planner.cpp:272-317) */
+void hoqp_oracle_gait_sample(int N, int n_steps, double duration, const int *schedule, double apex,
+			     int fix_derivatives, const double *time, const double *vel_cmd, const double *stance0,
+			     double *leg_cmd, int *contact);
+void hoqp_oracle_standup_sample(int N, double seconds, double target_height, const double *time,
+				const double *curr_pose, double *base_cmd, int *contact);
+
 #endif
 
 typedef struct {
@@ -77,6 +84,13 @@ int hoqp_oracle_wbc_solve_batch(const hoqp_oracle_cfg *cfg, const hoqp_oracle_wb
 
 #ifdef __cplusplus
 }
+/* N3: command / gait sampler (leg_planner.cpp, base_planner.cpp:272-317) */
+void hoqp_oracle_gait_sample(int N, int n_steps, double duration, const int *schedule, double apex,
+			     int fix_derivatives, const double *time, const double *vel_cmd, const double *stance0,
+			     double *leg_cmd, int *contact);
+void hoqp_oracle_standup_sample(int N, double seconds, double target_height, const double *time,
+				const double *curr_pose, double *base_cmd, int *contact);
+
 #endif
 /* Post-solve step: Integrator::Integrate twice (integrator.cpp:31-36, called by
  * WholeBodyController::SetJointCmdFromIntegrators, whole_body_controller.cpp:148-155) and
@@ -84,5 +98,12 @@ int hoqp_oracle_wbc_solve_batch(const hoqp_oracle_cfg *cfg, const hoqp_oracle_wb
  * qd_cmd are updated in place; dt is an argument (the reference reads the wall clock). */
 void hoqp_oracle_wbc_poststep(int N, double dt, double kp, double kd, const double *qdd, const double *tau_ff,
 			      const double *q_j, const double *qd_j, double *q_cmd, double *qd_cmd, double *tau_cmd);
+
+/* N3: command / gait sampler (leg_planner.cpp, base_planner.cpp:272-317) */
+void hoqp_oracle_gait_sample(int N, int n_steps, double duration, const int *schedule, double apex,
+			     int fix_derivatives, const double *time, const double *vel_cmd, const double *stance0,
+			     double *leg_cmd, int *contact);
+void hoqp_oracle_standup_sample(int N, double seconds, double target_height, const double *time,
+				const double *curr_pose, double *base_cmd, int *contact);
 
 #endif

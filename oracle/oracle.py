@@ -66,6 +66,10 @@ def lib():
     return _lib
 
 
+_DP = C.POINTER(C.c_double)
+_IP = C.POINTER(C.c_int)
+
+
 def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
@@ -226,3 +230,48 @@ def wbc_poststep(dt, kp, kd, qdd, tau_ff, q_j, qd_j, q_cmd, qd_cmd):
     f.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double] + [C.POINTER(C.c_double)] * 7
     f(N, dt, kp, kd, *[_dp(a) for a in arrs], _dp(tau))
     return arrs[4], arrs[5], tau
+
+
+# gait schedules of MotionPlanner::CreateSimpleSequence / CreateCrawlSequence (motion_planner.cpp:536-575):
+# (n_steps, duration, [4][n_steps] contact schedule, legs LF RF LH RH)
+def _schedule(n, swings):
+    sch = np.ones((4, n), dtype=np.int32)
+    for leg, steps in enumerate(swings):
+        sch[leg, list(steps)] = 0
+    return sch
+
+
+GAITS = {
+    "simple": (12, 20.0, _schedule(12, [(10,), (7,), (4,), (1,)])),
+    "crawl": (20, 10.0, _schedule(20, [range(14, 19), range(4, 9), range(11, 16), range(1, 6)])),
+}
+
+
+def gait_sample(gait, time, vel_cmd, stance0, apex=0.2, fix_derivatives=False):
+    """N3: (leg_cmd [N,36], contact [N,4]) at the given times; gait = key of GAITS or (n, duration, schedule)."""
+    n, dur, sch = GAITS[gait] if isinstance(gait, str) else gait
+    sch = np.ascontiguousarray(sch, dtype=np.int32)
+    time = np.ascontiguousarray(time, dtype=np.float64)
+    N = time.shape[0]
+    vel = np.ascontiguousarray(vel_cmd, dtype=np.float64).reshape(N, 2)
+    st0 = np.ascontiguousarray(stance0, dtype=np.float64).reshape(N, 4, 2)
+    leg_cmd = np.zeros((N, 36))
+    contact = np.zeros((N, 4), dtype=np.int32)
+    f = lib().hoqp_oracle_gait_sample
+    f.restype = None
+    f.argtypes = [C.c_int, C.c_int, C.c_double, _IP, C.c_double, C.c_int, _DP, _DP, _DP, _DP, _IP]
+    f(N, n, dur, _ip(sch), apex, int(fix_derivatives), _dp(time), _dp(vel), _dp(st0), _dp(leg_cmd), _ip(contact))
+    return leg_cmd, contact
+
+
+def standup_sample(time, seconds, target_height, curr_pose):
+    time = np.ascontiguousarray(time, dtype=np.float64)
+    N = time.shape[0]
+    pose = np.ascontiguousarray(curr_pose, dtype=np.float64).reshape(N, 3)
+    base_cmd = np.zeros((N, 9))
+    contact = np.zeros((N, 4), dtype=np.int32)
+    f = lib().hoqp_oracle_standup_sample
+    f.restype = None
+    f.argtypes = [C.c_int, C.c_double, C.c_double, _DP, _DP, _DP, _IP]
+    f(N, seconds, target_height, _dp(time), _dp(pose), _dp(base_cmd), _ip(contact))
+    return base_cmd, contact

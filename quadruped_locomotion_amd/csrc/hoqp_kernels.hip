@@ -23,6 +23,7 @@
 #include "hoqp_device.hpp"
 #include "hoqp_solve.hpp"
 #include "wbc_dynamics.hpp"
+#include "gait_sampler.hpp"
 
 namespace hoqp {
 
@@ -738,6 +739,70 @@ extern "C" int hoqp_wbc_poststep_batched(hoqp_handle *h, int batch, double dt, d
 		return fail(h, -1, "batch too large");
 	hipLaunchKernelGGL(wbc_poststep_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
 			   (int)total, dt, kp, kd, qdd, tau_ff, q_j, qd_j, q_cmd, qd_cmd, tau_cmd);
+	HIP_OK(h, hipGetLastError());
+	return 0;
+}
+
+extern "C" int hoqp_default_gait(int kind, hoqp_gait *g)
+{
+	if (!g || (kind != 0 && kind != 1))
+		return -1;
+	std::memset(g, 0, sizeof(*g));
+	g->apex_height = 0.2;  // leg_planner.cpp:241
+	g->fix_derivatives = 0;
+	// swing steps per leg (LF, RF, LH, RH), motion_planner.cpp:543-547 / 564-568
+	static const int simple_first[4] = {10, 7, 4, 1}, crawl_first[4] = {14, 4, 11, 1};
+	g->n_steps = kind == 0 ? 12 : 20;
+	g->duration = kind == 0 ? 20.0 : 10.0;
+	const int len = kind == 0 ? 1 : 5;
+	for (int leg = 0; leg < 4; ++leg) {
+		unsigned bits = (g->n_steps == 32) ? ~0u : ((1u << g->n_steps) - 1u);
+		const int first = kind == 0 ? simple_first[leg] : crawl_first[leg];
+		for (int s = first; s < first + len; ++s)
+			bits &= ~(1u << s);
+		g->contact_bits[leg] = bits;
+	}
+	return 0;
+}
+
+extern "C" int hoqp_gait_sample_batched(hoqp_handle *h, const hoqp_gait *g, int batch, const double *time,
+					const double *vel_cmd, const double *stance0, double *leg_cmd, int *contact,
+					void *stream)
+{
+	if (!h)
+		return -1;
+	if (!g || g->n_steps < 1 || g->n_steps > HOQP_MAX_GAIT_STEPS || !(g->duration > 0.0))
+		return fail(h, -1, "hoqp_gait_sample_batched: gait with 1..HOQP_MAX_GAIT_STEPS steps and duration > 0 required");
+	if (batch < 0 || batch > 0x1fffffff)
+		return fail(h, -1, "batch out of range");
+	if (!time || !vel_cmd || !stance0 || !leg_cmd || !contact)
+		return fail(h, -1, "hoqp_gait_sample_batched: null array");
+	if (batch == 0)
+		return 0;
+	HIP_OK(h, hipSetDevice(h->cfg.device));
+	hipLaunchKernelGGL(gait_sample_kernel, dim3((4u * batch + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, *g, batch,
+			   time, vel_cmd, stance0, leg_cmd, contact);
+	HIP_OK(h, hipGetLastError());
+	return 0;
+}
+
+extern "C" int hoqp_standup_sample_batched(hoqp_handle *h, int batch, const double *time, double seconds_to_standup,
+					   double target_height, const double *curr_pose, double *base_cmd, int *contact,
+					   void *stream)
+{
+	if (!h)
+		return -1;
+	if (batch < 0)
+		return fail(h, -1, "negative batch");
+	if (!(seconds_to_standup > 0.0))
+		return fail(h, -1, "hoqp_standup_sample_batched: seconds_to_standup must be positive");
+	if (!time || !curr_pose || !base_cmd)
+		return fail(h, -1, "hoqp_standup_sample_batched: null array");
+	if (batch == 0)
+		return 0;
+	HIP_OK(h, hipSetDevice(h->cfg.device));
+	hipLaunchKernelGGL(standup_sample_kernel, dim3((batch + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, batch,
+			   seconds_to_standup, target_height, time, curr_pose, base_cmd, contact);
 	HIP_OK(h, hipGetLastError());
 	return 0;
 }

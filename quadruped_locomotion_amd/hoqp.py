@@ -33,7 +33,8 @@ STATUS_NONFINITE = 0x08
 EXPORTS = (
     "hoqp_default_config", "hoqp_create", "hoqp_destroy", "hoqp_last_error_string",
     "hoqp_solve_tasks_batched", "hoqp_solve_wbc_batched", "hoqp_solve_tasks_host", "hoqp_solve_wbc_host",
-    "hoqp_default_quadruped_model", "hoqp_wbc_dynamics_batched", "hoqp_wbc_dynamics_host", "hoqp_wbc_poststep_batched", "hoqp_synchronize",
+    "hoqp_default_quadruped_model", "hoqp_wbc_dynamics_batched", "hoqp_wbc_dynamics_host", "hoqp_wbc_poststep_batched",
+    "hoqp_default_gait", "hoqp_gait_sample_batched", "hoqp_standup_sample_batched", "hoqp_synchronize",
     "hoqp_kernel_time_ms", "hoqp_selftest", "hoqp_lds_bytes",
 )
 
@@ -54,6 +55,12 @@ class QuadrupedModel(C.Structure):
                 ("shank_mass", C.c_double)] + [(n, C.c_double * 3) for n in (
                     "base_inertia", "hip_inertia", "thigh_inertia", "shank_inertia", "haa_off", "hfe_off", "kfe_off",
                     "foot_off", "hip_com", "thigh_com", "shank_com")] + [("gravity", C.c_double)]
+
+
+class Gait(C.Structure):
+    """hoqp_gait (GaitSequence of the reference as bit masks per leg + swing apex + derivative switch)."""
+    _fields_ = [("n_steps", C.c_int), ("duration", C.c_double), ("contact_bits", C.c_uint * 4),
+                ("apex_height", C.c_double), ("fix_derivatives", C.c_int)]
 
 
 class TaskBatch(C.Structure):
@@ -113,6 +120,9 @@ def load_library():
         lib.hoqp_default_quadruped_model.restype = None
         lib.hoqp_wbc_dynamics_batched.argtypes = [C.c_void_p, C.POINTER(QuadrupedModel), C.c_int, C.c_void_p, C.c_void_p,
                                                   C.c_int] + [C.c_void_p] * 7
+        lib.hoqp_default_gait.argtypes = [C.c_int, C.POINTER(Gait)]
+        lib.hoqp_gait_sample_batched.argtypes = [C.c_void_p, C.POINTER(Gait), C.c_int] + [C.c_void_p] * 6
+        lib.hoqp_standup_sample_batched.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_double] + [C.c_void_p] * 4
         lib.hoqp_wbc_poststep_batched.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double] + [C.c_void_p] * 8
         lib.hoqp_kernel_time_ms.argtypes = [C.c_void_p, C.c_int, _dp, _ip]
         lib.hoqp_selftest.argtypes = [C.c_void_p]
@@ -134,6 +144,16 @@ def default_config(mode: str = "reference", device: int = 0, **kw) -> Config:
     for k, v in kw.items():
         setattr(cfg, k, v)
     return cfg
+
+
+def default_gait(kind: str = "simple", **kw) -> Gait:
+    """MotionPlanner::CreateSimpleSequence ("simple") / CreateCrawlSequence ("crawl")."""
+    g = Gait()
+    if load_library().hoqp_default_gait({"simple": 0, "crawl": 1}[kind], C.byref(g)) != 0:
+        raise ValueError(kind)
+    for k, v in kw.items():
+        setattr(g, k, v)
+    return g
 
 
 def lds_bytes(n, m, p):
@@ -315,6 +335,37 @@ class HoQpSolver:
         self._check(self.lib.hoqp_wbc_poststep_batched(self.h, B, C.c_double(dt), C.c_double(kp), C.c_double(kd),
                                                        *ptrs, self._stream()), "hoqp_wbc_poststep_batched")
         return tau_cmd
+
+    # -- command sampler -------------------------------------
+    def gait_sample(self, gait, time, vel_cmd, stance0):
+        """leg_cmd [B,36] and contact [B,4] of the gait (a Gait, or "simple" / "crawl") at time [B] for
+        plans made from stance0 [B,4,2] under vel_cmd [B,2]; float64 CUDA tensors."""
+        t = self.torch
+        if isinstance(gait, str):
+            gait = default_gait(gait)
+        B = time.shape[0]
+        for name, arr, shape in (("time", time, (B,)), ("vel_cmd", vel_cmd, (B, 2)), ("stance0", stance0, (B, 4, 2))):
+            assert arr.dtype == t.float64 and arr.is_contiguous() and arr.is_cuda and tuple(arr.shape) == shape, name
+        leg_cmd = t.zeros(B, 36, dtype=t.float64, device=self.device)
+        contact = t.zeros(B, 4, dtype=t.int32, device=self.device)
+        self._check(self.lib.hoqp_gait_sample_batched(self.h, C.byref(gait), B, time.data_ptr(), vel_cmd.data_ptr(),
+                                                      stance0.data_ptr(), leg_cmd.data_ptr(), contact.data_ptr(),
+                                                      self._stream()), "hoqp_gait_sample_batched")
+        return leg_cmd, contact
+
+    def standup_sample(self, time, seconds, target_height, curr_pose):
+        """base_cmd [B,9] and contact [B,4] of the stand-up ramp at time [B] from curr_pose [B,3]."""
+        t = self.torch
+        B = time.shape[0]
+        assert time.dtype == t.float64 and time.is_cuda and time.is_contiguous()
+        assert curr_pose.dtype == t.float64 and curr_pose.is_cuda and curr_pose.is_contiguous() and tuple(curr_pose.shape) == (B, 3)
+        base_cmd = t.zeros(B, 9, dtype=t.float64, device=self.device)
+        contact = t.zeros(B, 4, dtype=t.int32, device=self.device)
+        self._check(self.lib.hoqp_standup_sample_batched(self.h, B, time.data_ptr(), C.c_double(seconds),
+                                                         C.c_double(target_height), curr_pose.data_ptr(),
+                                                         base_cmd.data_ptr(), contact.data_ptr(), self._stream()),
+                    "hoqp_standup_sample_batched")
+        return base_cmd, contact
 
     def solve_wbc(self, dinp, out=None):
         t = self.torch

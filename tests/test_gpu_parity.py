@@ -416,3 +416,76 @@ def test_wbc_device_pipeline(solver_factory, oracle):
     q_ref = st["q"][:, 7:19] + 2.5e-3 * qd_ref
     tau_ref = 40.0 * (q_ref - st["q"][:, 7:19]) + 1.0 * (qd_ref - st["u"][:, 6:18]) + ref["tau"]
     _close(tau_cmd.cpu().numpy(), tau_ref, "tau_cmd")
+
+
+@pytest.mark.parametrize("kind", ["simple", "crawl"])
+@pytest.mark.parametrize("fix", [False, True])
+def test_gait_sampler(solver_factory, oracle, kind, fix):
+    """N3: swing-leg commands and contact pattern on the device against the oracle; same formulas, so
+    1e-12 (fused multiply-add contraction is the only freedom), contact pattern exact."""
+    import torch
+
+    rng = np.random.default_rng(31)
+    B = 5000
+    dur = oracle.GAITS[kind][1]
+    time = rng.uniform(0.0, 3.0 * dur, B)
+    time[:40] = np.arange(40) * (dur / oracle.GAITS[kind][0])       # exactly on the step boundaries
+    vel = rng.normal(0.0, 0.2, (B, 2))
+    stance = rng.normal(0.0, 0.3, (B, 4, 2))
+    s = solver_factory("reference")
+    from quadruped_locomotion_amd import hoqp
+
+    g = hoqp.default_gait(kind, fix_derivatives=int(fix), apex_height=0.15)
+    lc, ct = s.gait_sample(g, torch.as_tensor(time).cuda(), torch.as_tensor(vel).cuda(), torch.as_tensor(stance).cuda())
+    s.synchronize()
+    lr, cr = oracle.gait_sample(kind, time, vel, stance, apex=0.15, fix_derivatives=fix)
+    onb = np.zeros(B, dtype=bool)
+    onb[:40] = True      # a time ON a boundary may fall either side of it after fmod / division rounding
+    assert np.array_equal(ct.cpu().numpy()[~onb], cr[~onb])
+    err = np.abs(lc.cpu().numpy() - lr) / np.maximum(1.0, np.abs(lr))
+    assert err[~onb].max() < 1e-12
+    assert (ct.cpu().numpy()[onb] != cr[onb]).sum() == 0 and err[onb].max() < 1e-9
+
+
+def test_standup_sampler_and_command_pipeline(solver_factory, oracle):
+    """N3 -> N1 -> solve on the device: commands and contact pattern from the sampler (crawl gait,
+    corrected derivatives), dynamics terms from the producer, then the WBC solve; against the oracle
+    fed with the oracle's own sampler outputs and the numpy model."""
+    import torch
+
+    rng = np.random.default_rng(32)
+    B = 512
+    s = solver_factory("reference")
+    t = rng.uniform(0.0, 4.0, B)
+    pose = rng.normal(0.0, 0.1, (B, 3))
+    bc, ct1 = s.standup_sample(torch.as_tensor(t).cuda(), 2.0, 0.5, torch.as_tensor(pose).cuda())
+    s.synchronize()
+    br, cr1 = oracle.standup_sample(t, 2.0, 0.5, pose)
+    assert np.abs(bc.cpu().numpy() - br).max() < 1e-13 and np.array_equal(ct1.cpu().numpy(), cr1)
+
+    st = am.sample_states(B, 79, "stance")
+    inp0 = am.make_wbc_inputs(st)
+    time = rng.uniform(0.0, 10.0, B)
+    vel = np.tile([0.1, 0.02], (B, 1))
+    stance0 = inp0["footpos"][:, :, :2].copy()
+    lr, cr = oracle.gait_sample("crawl", time, vel, stance0, fix_derivatives=True)
+    inp = dict(inp0)     # (make_wbc_inputs treats a state's leg positions as offsets: set the commands after it)
+    inp["leg_cmd"], inp["contact"] = lr, cr
+    from quadruped_locomotion_amd import hoqp
+
+    g = hoqp.default_gait("crawl", fix_derivatives=1)
+    dq, du = torch.as_tensor(st["q"]).contiguous().cuda(), torch.as_tensor(st["u"]).contiguous().cuda()
+    dyn = s.wbc_dynamics(dq, du)
+    dst0 = dyn["footpos"][:, :, :2].contiguous()
+    lc, ct = s.gait_sample(g, torch.as_tensor(time).cuda(), torch.as_tensor(vel).cuda(), dst0)
+    dinp = s.to_device(inp)
+    for k in ("M", "h", "Jfoot", "Jdotu", "footpos", "Jb"):
+        dinp[k] = dyn[k]
+    dinp["leg_cmd"], dinp["contact"] = lc, ct
+    out = s.solve_wbc(dinp)
+    s.synchronize()
+    assert np.array_equal(ct.cpu().numpy(), cr) and (cr.sum(axis=1) < 4).sum() > B // 2 and (cr.sum(axis=1) == 2).sum() > 0
+    ref, rc = oracle.wbc_solve_batch(inp, oracle.default_cfg("reference"), oracle.default_wbc_params("reference"), threads=8)
+    assert rc == 0
+    _close(out["x"].cpu().numpy(), ref["x"], "x")
+    _close(out["tau"].cpu().numpy(), ref["tau"], "tau")

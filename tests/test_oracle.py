@@ -266,3 +266,53 @@ def test_poststep_known_answer(oracle):
     assert np.array_equal(qd, 5.0 * one)                 # 3 + 0.5 * 4
     assert np.array_equal(q, 3.5 * one)                  # 1 + 0.5 * 5
     assert np.array_equal(tau, (10 * 3.25 + 2 * 4.5 + 1) * one)
+
+
+# the two gait schedules of the reference (motion_planner.cpp:543-547, 564-568), rows LF RF LH RH
+SIMPLE = np.array([[1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 1],
+                   [1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1],
+                   [1, 1, 1, 1, 0, 1, 1, 1, 1, 1, 1, 1],
+                   [1, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1]])
+CRAWL = np.array([[1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 1],
+                  [1, 1, 1, 1, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1],
+                  [1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 1, 1, 1, 1],
+                  [1, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1]])
+STANCE = np.array([[0.3, 0.2], [0.3, -0.2], [-0.3, 0.2], [-0.3, -0.2]])
+
+
+def test_gait_sampler_known_answers(oracle):
+    """N3: gait schedules as in the reference; swing of RH in the simple gait (step 1 of 12 over 20 s)
+    evaluated by hand; the reference's velocity/acceleration commands repeat the position (its
+    evaluation bug), the corrected mode gives the derivatives; periodic in the gait duration."""
+    assert np.array_equal(oracle.GAITS["simple"][2], SIMPLE) and oracle.GAITS["simple"][:2] == (12, 20.0)
+    assert np.array_equal(oracle.GAITS["crawl"][2], CRAWL) and oracle.GAITS["crawl"][:2] == (20, 10.0)
+    st = 20.0 / 12.0
+    t = np.array([0.5 * st, st, 1.25 * st, 1.5 * st, 2.0 * st, 2.0 * st + 1e-9, 1.5 * st + 40.0])
+    N = t.size
+    vel = np.tile([0.12, -0.06], (N, 1))
+    lc, ct = oracle.gait_sample("simple", t, vel, np.tile(STANCE, (N, 1, 1)))
+    assert np.array_equal(ct[:, 3], [1, 0, 0, 0, 1, 1, 0]) and np.all(ct[:, :3] == 1)
+    assert np.all(lc[:, :9] == 0) and np.all(lc[0] == 0) and np.all(lc[5] == 0)      # stance legs / outside the swing
+    start, end = STANCE[3], STANCE[3] + st * vel[0]
+    for row, w in ((1, 0.0), (2, 0.25), (3, 0.5), (4, 1.0), (6, 0.5)):
+        want = np.r_[start + w * (end - start), 0.2 * (1.0 - (2.0 * w - 1.0) ** 2)]
+        assert np.allclose(lc[row, 9:12], want, atol=1e-12), row
+        assert np.allclose(lc[row, 21:24], want, atol=1e-12) and np.allclose(lc[row, 33:36], want, atol=1e-12)
+    lf, _ = oracle.gait_sample("simple", t, vel, np.tile(STANCE, (N, 1, 1)), fix_derivatives=True)
+    assert np.allclose(lf[:, :12], lc[:, :12], atol=0)
+    assert np.allclose(lf[3, 21:24], [0.12, -0.06, 0.0], atol=1e-12)                   # apex: no vertical speed
+    assert np.allclose(lf[2, 21:24], [0.12, -0.06, 0.2 * 2.0 * 0.5 / (0.5 * st)], atol=1e-12)
+    assert np.allclose(lf[3, 33:36], [0.0, 0.0, -2.0 * 0.2 / (0.5 * st) ** 2], atol=1e-12)
+    # crawl: five-step swings (LF and LH overlap for two steps), the foothold advances five steps' worth
+    tc = np.linspace(0.0, 9.99, 200)
+    lcc, ctc = oracle.gait_sample("crawl", tc, np.tile([0.1, 0.0], (200, 1)), np.tile(STANCE, (200, 1, 1)))
+    assert np.array_equal(ctc, CRAWL[:, (tc / 0.5).astype(int)].T) and ctc.sum(axis=1).min() == 2
+    sw = ctc[:, 0] == 0
+    assert np.all(lcc[sw, 2] > 0) and np.all(lcc[sw, 0] >= 0.3 - 1e-12) and np.all(lcc[sw, 0] <= 0.3 + 0.25 + 1e-12)
+
+
+def test_standup_sampler_known_answers(oracle):
+    bc, ct = oracle.standup_sample(np.array([0.0, 1.0, 2.0, 2.5]), 2.0, 0.5, np.tile([0.1, -0.2, 0.1], (4, 1)))
+    assert np.allclose(bc[:, 0], 0.1) and np.allclose(bc[:, 1], -0.2) and np.allclose(bc[:, 2], [0.1, 0.3, 0.5, 0.5])
+    assert np.allclose(bc[:, 5], [0.2, 0.2, 0.2, 0.0]) and np.all(bc[:, 3:5] == 0) and np.all(bc[:, 6:] == 0)
+    assert np.all(ct == 1)
