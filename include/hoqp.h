@@ -243,6 +243,16 @@ int hoqp_standup_sample_batched(hoqp_handle *h, int batch, const double *time, d
 				double target_height, const double *curr_pose, double *base_cmd, int *contact,
 				void *stream);
 
+/* SURVEY 8f N4.  Replaces: BasePlanner::PlanBaseWalkMotion (base_planner.cpp:7-19: the spline QP of
+ * FormulateOptimizationProblem, :162-266, n_segments quintic 2-D segments of unit duration from
+ * curr_pos [batch][2] to final_pos [batch][2] = the centroid of the last support polygon, :254-256) and
+ * EvalWalkTraj{Pos,Vel,Acc}AtT (:34-47, 100-142) at time [batch]: base_cmd [batch][9].
+ * fix_layout 0: as the reference, the solution is read back with rows and columns of the coefficient
+ * matrix exchanged (GeneratePolynomials, :77-98); 1: the trajectory that was optimised. */
+int hoqp_base_walk_sample_batched(hoqp_handle *h, int batch, const double *time, const double *curr_pos,
+				  const double *final_pos, double walking_height, int n_segments, int fix_layout,
+				  double *base_cmd, void *stream);
+
 /* Blocks until `stream` has drained; returns <0 if a kernel faulted. */
 int hoqp_synchronize(hoqp_handle *h, void *stream);
 

@@ -95,4 +95,51 @@ __global__ void standup_sample_kernel(int batch, double seconds, double target_h
 			contact[4 * i + leg] = 1;
 }
 
+// BasePlanner::PlanBaseWalkMotion + EvalWalkTraj{Pos,Vel,Acc}AtT (base_planner.cpp:7-19,
+// 100-142, 162-266).  The reference's program -- n quintic 2-D segments of unit duration, sampled
+// acceleration cost, position and velocity continuity, fixed end points -- has a zero-cost feasible
+// point, the straight line from the current position to the target at constant speed, and its KKT
+// matrix is non-singular, so that line IS the solution (the tests solve the literal KKT system on the
+// CPU and compare).  No per-instance factorization is left: segment k has
+// x(t) = p0x + (k + t) dx, y(t) = p0y + (k + t) dy in the program's variable order
+// alpha_k = [x coefficients; y coefficients].  The reference then reads the solution back as a
+// column-major 2 x 6 matrix (GeneratePolynomials, :77-98): C(0, d) = alpha[2d], C(1, d) = alpha[2d+1],
+// which turns the line into x = ax0 + ay0 t^3, y = ax1 + ay1 t^3; fix_layout = 1 evaluates the line.
+__global__ void base_walk_sample_kernel(int batch, int n_segments, int fix_layout, double walking_height,
+					const double *__restrict__ time, const double *__restrict__ curr_pos,
+					const double *__restrict__ final_pos, double *__restrict__ base_cmd)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= batch)
+		return;
+	const double t = time[i];
+	int k = 0;
+	while (((double)k + 1.0 < t) && (k + 1 < n_segments))  // EvalWalkTrajAtT, :103-106
+		++k;
+	const double tin = t - (double)k;
+	const double p0x = curr_pos[2 * i], p0y = curr_pos[2 * i + 1];
+	const double dx = (final_pos[2 * i] - p0x) / (double)n_segments, dy = (final_pos[2 * i + 1] - p0y) / (double)n_segments;
+	const double ax0 = p0x + (double)k * dx, ax1 = dx, ay0 = p0y + (double)k * dy, ay1 = dy;
+	double *o = base_cmd + (size_t)i * 9;
+	if (fix_layout) {
+		o[0] = ax0 + ax1 * tin;
+		o[1] = ay0 + ay1 * tin;
+		o[3] = ax1;
+		o[4] = ay1;
+		o[6] = 0.0;
+		o[7] = 0.0;
+	} else {
+		const double t2 = tin * tin;
+		o[0] = ax0 + ay0 * t2 * tin;
+		o[1] = ax1 + ay1 * t2 * tin;
+		o[3] = 3.0 * ay0 * t2;
+		o[4] = 3.0 * ay1 * t2;
+		o[6] = 6.0 * ay0 * tin;
+		o[7] = 6.0 * ay1 * tin;
+	}
+	o[2] = walking_height;  // :118, 123, 128
+	o[5] = 0.0;
+	o[8] = 0.0;
+}
+
 }  // namespace hoqp

@@ -807,6 +807,27 @@ extern "C" int hoqp_standup_sample_batched(hoqp_handle *h, int batch, const doub
 	return 0;
 }
 
+extern "C" int hoqp_base_walk_sample_batched(hoqp_handle *h, int batch, const double *time, const double *curr_pos,
+					     const double *final_pos, double walking_height, int n_segments, int fix_layout,
+					     double *base_cmd, void *stream)
+{
+	if (!h)
+		return -1;
+	if (batch < 0)
+		return fail(h, -1, "negative batch");
+	if (n_segments < 1)
+		return fail(h, -1, "hoqp_base_walk_sample_batched: n_segments must be positive");
+	if (!time || !curr_pos || !final_pos || !base_cmd)
+		return fail(h, -1, "hoqp_base_walk_sample_batched: null array");
+	if (batch == 0)
+		return 0;
+	HIP_OK(h, hipSetDevice(h->cfg.device));
+	hipLaunchKernelGGL(base_walk_sample_kernel, dim3((batch + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, batch,
+			   n_segments, fix_layout, walking_height, time, curr_pos, final_pos, base_cmd);
+	HIP_OK(h, hipGetLastError());
+	return 0;
+}
+
 // ---------------------------------------------------------------------------
 // host-buffer convenience entry points (single-instance drop-in use: the reference calls
 // CalcJointCmd once per 2.5 ms cycle with host Eigen data, whole_body_controller.cpp:97-107)

@@ -34,7 +34,8 @@ EXPORTS = (
     "hoqp_default_config", "hoqp_create", "hoqp_destroy", "hoqp_last_error_string",
     "hoqp_solve_tasks_batched", "hoqp_solve_wbc_batched", "hoqp_solve_tasks_host", "hoqp_solve_wbc_host",
     "hoqp_default_quadruped_model", "hoqp_wbc_dynamics_batched", "hoqp_wbc_dynamics_host", "hoqp_wbc_poststep_batched",
-    "hoqp_default_gait", "hoqp_gait_sample_batched", "hoqp_standup_sample_batched", "hoqp_synchronize",
+    "hoqp_default_gait", "hoqp_gait_sample_batched", "hoqp_standup_sample_batched",
+    "hoqp_base_walk_sample_batched", "hoqp_synchronize",
     "hoqp_kernel_time_ms", "hoqp_selftest", "hoqp_lds_bytes",
 )
 
@@ -123,6 +124,8 @@ def load_library():
         lib.hoqp_default_gait.argtypes = [C.c_int, C.POINTER(Gait)]
         lib.hoqp_gait_sample_batched.argtypes = [C.c_void_p, C.POINTER(Gait), C.c_int] + [C.c_void_p] * 6
         lib.hoqp_standup_sample_batched.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_double] + [C.c_void_p] * 4
+        lib.hoqp_base_walk_sample_batched.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
+                                                      C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         lib.hoqp_wbc_poststep_batched.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double] + [C.c_void_p] * 8
         lib.hoqp_kernel_time_ms.argtypes = [C.c_void_p, C.c_int, _dp, _ip]
         lib.hoqp_selftest.argtypes = [C.c_void_p]
@@ -366,6 +369,19 @@ class HoQpSolver:
                                                          base_cmd.data_ptr(), contact.data_ptr(), self._stream()),
                     "hoqp_standup_sample_batched")
         return base_cmd, contact
+
+    def base_walk_sample(self, time, curr_pos, final_pos, walking_height, n_segments=10, fix_layout=False):
+        """base_cmd [B,9] of the base walk trajectory at time [B]; curr_pos, final_pos [B,2]."""
+        t = self.torch
+        B = time.shape[0]
+        for name, arr, shape in (("time", time, (B,)), ("curr_pos", curr_pos, (B, 2)), ("final_pos", final_pos, (B, 2))):
+            assert arr.dtype == t.float64 and arr.is_contiguous() and arr.is_cuda and tuple(arr.shape) == shape, name
+        base_cmd = t.zeros(B, 9, dtype=t.float64, device=self.device)
+        self._check(self.lib.hoqp_base_walk_sample_batched(self.h, B, time.data_ptr(), curr_pos.data_ptr(),
+                                                           final_pos.data_ptr(), C.c_double(walking_height), n_segments,
+                                                           int(fix_layout), base_cmd.data_ptr(), self._stream()),
+                    "hoqp_base_walk_sample_batched")
+        return base_cmd
 
     def solve_wbc(self, dinp, out=None):
         t = self.torch

@@ -489,3 +489,23 @@ def test_standup_sampler_and_command_pipeline(solver_factory, oracle):
     assert rc == 0
     _close(out["x"].cpu().numpy(), ref["x"], "x")
     _close(out["tau"].cpu().numpy(), ref["tau"], "tau")
+
+
+@pytest.mark.parametrize("fix", [False, True])
+def test_base_walk_sampler(solver_factory, fix):
+    """N4: the device evaluates the closed-form solution of the base spline program; the oracle solves
+    the program's KKT system per instance (numpy) and evaluates it as the reference does."""
+    import torch
+    from oracle import base_planner_oracle as bp
+
+    rng = np.random.default_rng(41)
+    B = 64
+    time = rng.uniform(0.0, 12.0, B)
+    time[:11] = np.arange(11.0)               # segment boundaries
+    p0, pf = rng.normal(0.0, 0.3, (B, 2)), rng.normal(0.0, 0.5, (B, 2))
+    s = solver_factory("reference")
+    got = s.base_walk_sample(torch.as_tensor(time).cuda(), torch.as_tensor(p0).cuda(), torch.as_tensor(pf).cuda(), 0.47,
+                             fix_layout=fix).cpu().numpy()
+    for i in range(B):
+        want = bp.base_walk_eval(bp.base_walk_plan(p0[i], pf[i]), time[i], 0.47, fix_layout=fix)
+        assert np.abs(got[i] - want).max() < 1e-9 * max(1.0, np.abs(want).max()), (i, got[i], want)

@@ -316,3 +316,23 @@ def test_standup_sampler_known_answers(oracle):
     assert np.allclose(bc[:, 0], 0.1) and np.allclose(bc[:, 1], -0.2) and np.allclose(bc[:, 2], [0.1, 0.3, 0.5, 0.5])
     assert np.allclose(bc[:, 5], [0.2, 0.2, 0.2, 0.0]) and np.all(bc[:, 3:5] == 0) and np.all(bc[:, 6:] == 0)
     assert np.all(ct == 1)
+
+
+def test_base_walk_plan_is_the_straight_line():
+    """N4: the reference's spline QP (KKT solve of the literal program) has the constant-speed
+    straight line as its unique solution; the reference's read-back swaps the coefficient layout."""
+    from oracle import base_planner_oracle as bp
+
+    p0, pf = np.array([0.1, -0.2]), np.array([0.6, 0.3])
+    alpha = bp.base_walk_plan(p0, pf)
+    d = (pf - p0) / 10.0
+    for k in range(10):
+        want = np.zeros(12)
+        want[[0, 1, 6, 7]] = [p0[0] + k * d[0], d[0], p0[1] + k * d[1], d[1]]
+        assert np.abs(alpha[k] - want).max() < 1e-12
+    fixed = bp.base_walk_eval(alpha, 2.5, 0.45, fix_layout=True)
+    assert np.allclose(fixed, np.r_[p0 + 2.5 * d, 0.45, d, 0.0, 0.0, 0.0, 0.0], atol=1e-12)
+    ref = bp.base_walk_eval(alpha, 2.5, 0.45)
+    ax0, ay0 = p0 + 2 * d
+    assert np.allclose(ref[:2], [ax0 + ay0 * 0.125, d[0] + d[1] * 0.125], atol=1e-12)
+    assert np.allclose(bp.base_walk_eval(alpha, 25.0, 0.45, fix_layout=True)[:2], p0 + 25.0 * d, atol=1e-12)  # last segment extrapolates
