@@ -1931,55 +1931,65 @@ __global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
 	if (a.out.x && lane < a.n)
 		a.out.x[(size_t)inst * a.n + lane] = xi;
 	if (a.out.flags || a.out.eq_res_max || a.out.ineq_viol_max || a.out.active_mask) {
-		// one task row per lane; x broadcast from LDS
-		double xr[NR];
+		// one task row per quad (row = 16 * pass + c, lane s of the quad takes entries s, s+4, ...):
+		// every load instruction covers 16 rows x 32 contiguous bytes instead of 64 rows x 8 bytes
+		const int s = lane & 3, c = lane >> 2;
+		double xq[NT];
 #pragma unroll
-		for (int i = 0; i < NR; ++i)
-			xr[i] = l.x[i];
+		for (int t = 0; t < NT; ++t)
+			xq[t] = l.x[s + 4 * t];
 #pragma unroll
-		for (int i = 0; i < NR; ++i)
-			pin(xr[i]);
+		for (int t = 0; t < NT; ++t)
+			pin(xq[t]);
 #pragma unroll
-		for (int i = 0; i < NR; ++i)
-			xr[i] = sel(i < n, xr[i]);
+		for (int t = 0; t < NT; ++t)
+			xq[t] = sel(s + 4 * t < n, xq[t]);
+		// rows . x - rhs for `cnt` rows; returns the wave maximum of |.| (equalities) or of the signed
+		// value (inequalities) and, for inequalities, the bit mask of rows with value >= -1e-7
+		auto check_rows = [&](const double *rows_g, const double *rhs_g, int cnt, bool ineq, unsigned long long *act) {
+			double mx = ineq ? -1e300 : 0.0;
+			unsigned long long bits = 0ull;
+			for (int r0 = 0; r0 < cnt; r0 += 16) {
+				const int r = r0 + c;
+				const bool valid = r < cnt;
+				const double *row = rows_g + (size_t)(valid ? r : 0) * a.n;
+				double tv[NT];
+#pragma unroll
+				for (int t = 0; t < NT; ++t)
+					tv[t] = row[(s + 4 * t < a.n) ? s + 4 * t : 0];  // all loads in flight at once
+				const double rh = rhs_g[valid ? r : 0];
+				double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+				for (int t = 0; t < NT; t += 2) {
+					d0 = fma(tv[t], xq[t], d0);  // xq == 0 beyond n
+					d1 = fma(tv[t + 1], xq[t + 1], d1);
+				}
+				const double d = quad_sum(d0 + d1) - rh;
+				const double e = ineq ? d : fabs(d);
+				mx = valid ? fmax(mx, e) : mx;
+				if (ineq) {
+					const int pred = valid && e >= -1e-7;
+					const int mine = __shfl(pred, (lane * 4) & (kWave - 1));  // lane q < 16 <- quad q
+					const unsigned long long bm = __ballot(lane < 16 && mine);
+					if (r0 < 64)
+						bits |= bm << r0;
+				}
+			}
+			if (act)
+				*act = bits;
+			return wave_max(mx);
+		};
 		unsigned long long amask = 0ull;
 		int prow = 0;
 		for (int k = 0; k < a.L; ++k) {
 			const int m = uni(a.m_inst ? a.m_inst[(size_t)inst * a.L + k] : a.m[k]);
 			const int p = uni(a.p_inst ? a.p_inst[(size_t)inst * a.L + k] : a.p[k]);
 			double er = 0.0, iv = -1e300;
-			if (m > 0) {
-				double e = 0.0;
-				if (lane < m) {
-					const double *ar = a.A[k] + ((size_t)inst * a.m[k] + lane) * a.n;
-					double acc = -a.b[k][(size_t)inst * a.m[k] + lane];
-					double t[NR];
-#pragma unroll
-					for (int i = 0; i < NR; ++i)
-						t[i] = ar[i < n ? i : 0];  // all loads in flight at once
-#pragma unroll
-					for (int i = 0; i < NR; ++i)
-						acc = fma(t[i], xr[i], acc);  // xr[i >= n] == 0
-					e = fabs(acc);
-				}
-				er = wave_max(e);
-			}
+			if (m > 0)
+				er = check_rows(a.A[k] + (size_t)inst * a.m[k] * a.n, a.b[k] + (size_t)inst * a.m[k], m, false, nullptr);
 			if (p > 0) {
-				double e = -1e300;
-				if (lane < p) {
-					const double *dr = a.D[k] + ((size_t)inst * a.p[k] + lane) * a.n;
-					double acc = -a.f[k][(size_t)inst * a.p[k] + lane];
-					double t[NR];
-#pragma unroll
-					for (int i = 0; i < NR; ++i)
-						t[i] = dr[i < n ? i : 0];
-#pragma unroll
-					for (int i = 0; i < NR; ++i)
-						acc = fma(t[i], xr[i], acc);
-					e = acc;  // D x - f
-				}
-				iv = wave_max(e);
-				unsigned long long act = __ballot(lane < p && e >= -1e-7);
+				unsigned long long act = 0ull;
+				iv = check_rows(a.D[k] + (size_t)inst * a.p[k] * a.n, a.f[k] + (size_t)inst * a.p[k], p, true, &act);
 				if (prow < 64)
 					amask |= act << prow;
 			}
