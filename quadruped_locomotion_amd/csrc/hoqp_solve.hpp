@@ -972,45 +972,42 @@ __device__ __forceinline__ void project_task_mfma(const double *__restrict__ row
 						  bool to_T, int P, const Lds &l)
 {
 	const int lane = lane_id();
-	const int c = lane & 31, h = lane >> 5;
 	const int j16 = lane & 15, q4 = lane >> 4;
-	const int cc = (c < nstore) ? c : 0;
 	const bool two = nz + 1 > 16;  // second block of 16 output columns needed
-	double pre[CHUNK / 2];
-	double rv_next;
+	// The A operand of the 16x16x4 tile is A[i = lane % 16][k = lane / 16]: each lane loads its own
+	// entries straight from the task rows (16 rows x 32 contiguous bytes per load instruction); the
+	// next chunk's loads are in flight during the multiply.
+	double pre[NR / 4], rpre[4];
 	auto fetch = [&](int r0) {
 		const int nr = min(CHUNK, rows - r0);
+		const double *row = rows_g + (size_t)(r0 + (j16 < nr ? j16 : 0)) * nstore;
 #pragma unroll
-		for (int t = 0; t < CHUNK / 2; ++t) {
-			const int r = 2 * t + h;
-			pre[t] = rows_g[(size_t)(r0 + (r < nr ? r : 0)) * nstore + cc];
+		for (int kb = 0; kb < NR / 4; ++kb) {
+			const int k = 4 * kb + q4;
+			pre[kb] = row[k < nstore ? k : 0];  // bm is zero for k >= n
 		}
-		rv_next = rhs_g[r0 + (lane < nr ? lane : 0)];
+#pragma unroll
+		for (int r = 0; r < 4; ++r)
+			rpre[r] = rhs_g[r0 + (q4 + 4 * r < nr ? q4 + 4 * r : 0)];
 	};
 	fetch(0);
 	for (int r0 = 0; r0 < rows; r0 += CHUNK) {
 		const int nr = min(CHUNK, rows - r0);
-		wave_sync();  // readers of the previous chunk are done with S and tmp
-#pragma unroll
-		for (int t = 0; t < CHUNK / 2; ++t)
-			l.S[(2 * t + h) * SROW + c] = pre[t];
-		l.tmp[lane] = rv_next;
-		wave_sync();
-		if (r0 + CHUNK < rows)
-			fetch(r0 + CHUNK);
 		double av[NR / 4], rvr[4];
 #pragma unroll
 		for (int kb = 0; kb < NR / 4; ++kb)
-			av[kb] = l.S[j16 * SROW + 4 * kb + q4];
+			av[kb] = pre[kb];
 #pragma unroll
 		for (int r = 0; r < 4; ++r)
-			rvr[r] = l.tmp[q4 + 4 * r];
+			rvr[r] = rpre[r];
 #pragma unroll
 		for (int kb = 0; kb < NR / 4; ++kb)
 			pin(av[kb]);
 #pragma unroll
 		for (int r = 0; r < 4; ++r)
 			pin(rvr[r]);
+		if (r0 + CHUNK < rows)
+			fetch(r0 + CHUNK);
 		d4v acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
 		if (two) {
 #pragma unroll
