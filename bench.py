@@ -119,8 +119,15 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if os.environ.get("HOQP_BENCH_REHEARSE"):
+            # rehearsal of the N > 1 code path on a one-GPU box: every rank on device 0, gloo instead of
+            # RCCL (RCCL refuses two ranks on one device).  Not a measurement.
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from quadruped_locomotion_amd import anymal_model as am
     from quadruped_locomotion_amd import hoqp
@@ -199,7 +206,8 @@ def main():
         barrier()
         gather_ms = (time.perf_counter() - g0) * 1e3
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=solver.device)
+        tmax = torch.tensor([elapsed], dtype=torch.float64,
+                            device="cpu" if dist.get_backend() == "gloo" else solver.device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

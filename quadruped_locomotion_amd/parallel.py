@@ -26,8 +26,9 @@ def gather_solutions(local: dict, total: int, dst: int = 0, group=None):
     rank = dist.get_rank(group)
     per = -(-total // world)
     out = {} if rank == dst else None
+    host = dist.get_backend(group) == "gloo"   # gloo gathers host tensors only (CPU tests, rehearsals)
     for key in sorted(local):
-        t = local[key]
+        t = local[key].cpu() if host else local[key]
         pad = per - t.shape[0]
         if pad:
             t = torch.cat([t, t.new_zeros((pad,) + tuple(t.shape[1:]))], dim=0)
@@ -42,6 +43,13 @@ def gather_solutions(local: dict, total: int, dst: int = 0, group=None):
 def reduce_stats(max_stats: torch.Tensor, sum_stats: torch.Tensor, group=None):
     """All-reduce residual statistics: element-wise MAX of `max_stats` (max residuals /
     violations), SUM of `sum_stats` (counts, iteration totals).  In place; returns both."""
+    if dist.get_backend(group) == "gloo" and max_stats.is_cuda:
+        mx, sm = max_stats.cpu(), sum_stats.cpu()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM, group=group)
+        max_stats.copy_(mx)
+        sum_stats.copy_(sm)
+        return max_stats, sum_stats
     dist.all_reduce(max_stats, op=dist.ReduceOp.MAX, group=group)
     dist.all_reduce(sum_stats, op=dist.ReduceOp.SUM, group=group)
     return max_stats, sum_stats
