@@ -14,7 +14,7 @@
 //
 // One wavefront per state.  Phase 1: lane b < 13 is one rigid body (base, then hip/thigh/shank of
 // each leg), lanes 13..16 the four feet; each walks its leg's chain and leaves the body's
-// Jacobians, world inertia and bias wrench in LDS.  Phase 2: the 324 entries of
+// Jacobians, world inertia (and its product with the angular Jacobian) and bias wrench in LDS.  Phase 2: the 324 entries of
 // M = sum_b m Jv'Jv + Jw' I_w Jw are spread over the lanes.  FLOP-light, latency-bound, 4 KB out.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -47,12 +47,14 @@ __device__ __forceinline__ V3 mul(const M3 &R, V3 v) { return R.c0 * v.x + R.c1 
 __device__ __forceinline__ M3 mul(const M3 &A, const M3 &B) { return {mul(A, B.c0), mul(A, B.c1), mul(A, B.c2)}; }
 __device__ __forceinline__ M3 rot_x(double a)
 {
-	const double c = cos(a), s = sin(a);
+	double s, c;
+	sincos(a, &s, &c);
 	return {v3(1, 0, 0), v3(0, c, s), v3(0, -s, c)};
 }
 __device__ __forceinline__ M3 rot_y(double a)
 {
-	const double c = cos(a), s = sin(a);
+	double s, c;
+	sincos(a, &s, &c);
 	return {v3(c, 0, -s), v3(0, 1, 0), v3(s, 0, c)};
 }
 __device__ __forceinline__ V3 ld3(const double *p) { return {p[0], p[1], p[2]}; }
@@ -194,6 +196,21 @@ __global__ void __launch_bounds__(kWave) wbc_dynamics_kernel(hoqp_quadruped_mode
 			Iw[8] = s0.z * R.c0.z + s1.z * R.c1.z + s2.z * R.c2.z;
 			for (int i = 0; i < 9; ++i)
 				B[IW + i] = Iw[i];
+			// I_w J_w (3 x 18): the base angular columns are I_w itself, a joint column is I_w a_joint
+			auto iw_col = [&](int cj, V3 ax) {
+				B[IJ + 0 * NU_ + cj] = Iw[0] * ax.x + Iw[1] * ax.y + Iw[2] * ax.z;
+				B[IJ + 1 * NU_ + cj] = Iw[3] * ax.x + Iw[4] * ax.y + Iw[5] * ax.z;
+				B[IJ + 2 * NU_ + cj] = Iw[6] * ax.x + Iw[7] * ax.y + Iw[8] * ax.z;
+			};
+			for (int k = 0; k < 3; ++k)
+				for (int jj = 0; jj < 3; ++jj)
+					B[IJ + k * NU_ + jj] = Iw[3 * k + jj];
+			if (depth >= 1)
+				iw_col(6 + leg, a1);
+			if (depth >= 2)
+				iw_col(10 + leg, a2);
+			if (depth >= 3)
+				iw_col(14 + leg, a3);
 			// bias wrench: f = m a (- m g), t = I_w alpha + w x (I_w w)
 			V3 wf = acc * mass;
 			if (include_gravity)
@@ -209,20 +226,40 @@ __global__ void __launch_bounds__(kWave) wbc_dynamics_kernel(hoqp_quadruped_mode
 		}
 	}
 	__syncthreads();
-	// I_w J_w per body (3 x 18)
-	for (int e = lane; e < NB * 54; e += kWave) {
-		const int b = e / 54, rem = e - b * 54, k = rem / NU_, j = rem - k * NU_;
-		const double *B = sm + b * BSTR;
-		sm[b * BSTR + IJ + rem] =
-			B[IW + 3 * k] * B[JW + j] + B[IW + 3 * k + 1] * B[JW + NU_ + j] + B[IW + 3 * k + 2] * B[JW + 2 * NU_ + j];
-	}
-	__syncthreads();
 
 	// ---- phase 2: M = sym( sum_b m Jv'Jv + Jw' (I_w Jw) ),  h = sum_b Jv' f + Jw' t ----
-	for (int e = lane; e < NU_ * NU_; e += kWave) {
-		const int i = e / NU_, j = e - i * NU_;
+	// A joint column (leg l, depth d) is non-zero only in the bodies of leg l at depth >= d, so an
+	// entry with a joint index visits at most three bodies (none if its two joints sit on different
+	// legs); only the 6 x 6 base block sums over all 13.  The base block takes the first 36 lanes of
+	// the first pass, so the long loop runs once.
+	auto bodies_of = [&](int c, int &lo, int &hi) {  // bodies in which column c >= 6 is non-zero
+		const int l = (c - 6) & 3, d = (c - 6) >> 2;
+		lo = 1 + 3 * l + d;
+		hi = 1 + 3 * l + 3;
+	};
+	for (int idx = lane; idx < NU_ * NU_; idx += kWave) {
+		int i, j, lo = 0, hi = NB;
+		if (idx < 36) {
+			i = idx / 6, j = idx - 6 * i;
+		} else if (idx < 36 + 72) {
+			const int t = idx - 36;
+			i = t / 12, j = 6 + (t - 12 * i);
+			bodies_of(j, lo, hi);
+		} else {
+			const int t = idx - 108;
+			i = 6 + t / NU_, j = t - NU_ * (i - 6);
+			bodies_of(i, lo, hi);
+			if (j >= 6) {
+				int lo2, hi2;
+				bodies_of(j, lo2, hi2);
+				if (hi2 != hi)
+					hi = lo;  // different legs: no common body
+				else
+					lo = lo2 > lo ? lo2 : lo;
+			}
+		}
 		double sij = 0.0, sji = 0.0;
-		for (int b = 0; b < NB; ++b) {
+		for (int b = lo; b < hi; ++b) {
 			const double *B = sm + b * BSTR;
 			const double mass = B[MS];
 #pragma unroll
@@ -234,11 +271,14 @@ __global__ void __launch_bounds__(kWave) wbc_dynamics_kernel(hoqp_quadruped_mode
 				sji = fma(B[JW + k * NU_ + j], B[IJ + k * NU_ + i], sji);
 			}
 		}
-		Mg[(size_t)inst * NU_ * NU_ + e] = 0.5 * (sij + sji);
+		Mg[(size_t)inst * NU_ * NU_ + i * NU_ + j] = 0.5 * (sij + sji);
 	}
 	if (lane < NU_) {
+		int lo = 0, hi = NB;
+		if (lane >= 6)
+			bodies_of(lane, lo, hi);
 		double acc = 0.0;
-		for (int b = 0; b < NB; ++b) {
+		for (int b = lo; b < hi; ++b) {
 			const double *B = sm + b * BSTR;
 #pragma unroll
 			for (int k = 0; k < 3; ++k) {

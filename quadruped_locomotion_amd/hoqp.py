@@ -349,8 +349,8 @@ class HoQpSolver:
         B = time.shape[0]
         for name, arr, shape in (("time", time, (B,)), ("vel_cmd", vel_cmd, (B, 2)), ("stance0", stance0, (B, 4, 2))):
             assert arr.dtype == t.float64 and arr.is_contiguous() and arr.is_cuda and tuple(arr.shape) == shape, name
-        leg_cmd = t.zeros(B, 36, dtype=t.float64, device=self.device)
-        contact = t.zeros(B, 4, dtype=t.int32, device=self.device)
+        leg_cmd = t.empty(B, 36, dtype=t.float64, device=self.device)
+        contact = t.empty(B, 4, dtype=t.int32, device=self.device)
         self._check(self.lib.hoqp_gait_sample_batched(self.h, C.byref(gait), B, time.data_ptr(), vel_cmd.data_ptr(),
                                                       stance0.data_ptr(), leg_cmd.data_ptr(), contact.data_ptr(),
                                                       self._stream()), "hoqp_gait_sample_batched")
@@ -362,8 +362,8 @@ class HoQpSolver:
         B = time.shape[0]
         assert time.dtype == t.float64 and time.is_cuda and time.is_contiguous()
         assert curr_pose.dtype == t.float64 and curr_pose.is_cuda and curr_pose.is_contiguous() and tuple(curr_pose.shape) == (B, 3)
-        base_cmd = t.zeros(B, 9, dtype=t.float64, device=self.device)
-        contact = t.zeros(B, 4, dtype=t.int32, device=self.device)
+        base_cmd = t.empty(B, 9, dtype=t.float64, device=self.device)
+        contact = t.empty(B, 4, dtype=t.int32, device=self.device)
         self._check(self.lib.hoqp_standup_sample_batched(self.h, B, time.data_ptr(), C.c_double(seconds),
                                                          C.c_double(target_height), curr_pose.data_ptr(),
                                                          base_cmd.data_ptr(), contact.data_ptr(), self._stream()),
@@ -376,7 +376,7 @@ class HoQpSolver:
         B = time.shape[0]
         for name, arr, shape in (("time", time, (B,)), ("curr_pos", curr_pos, (B, 2)), ("final_pos", final_pos, (B, 2))):
             assert arr.dtype == t.float64 and arr.is_contiguous() and arr.is_cuda and tuple(arr.shape) == shape, name
-        base_cmd = t.zeros(B, 9, dtype=t.float64, device=self.device)
+        base_cmd = t.empty(B, 9, dtype=t.float64, device=self.device)
         self._check(self.lib.hoqp_base_walk_sample_batched(self.h, B, time.data_ptr(), curr_pos.data_ptr(),
                                                            final_pos.data_ptr(), C.c_double(walking_height), n_segments,
                                                            int(fix_layout), base_cmd.data_ptr(), self._stream()),
