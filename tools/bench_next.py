@@ -68,6 +68,29 @@ def main():
     p0, pf = f64(B, 2), f64(B, 2)
     row("N4 hoqp_base_walk_sample_batched", timed(lambda: s.base_walk_sample(time, p0, pf, 0.5), args.steps),
         8 * (1 + 2 + 2 + 9), "one thread per state; closed form of the spline program")
+    # the whole device-resident cycle: commands (N3) -> dynamics terms (N1) -> WBC solve -> post-solve step (N2)
+    inp = am.make_wbc_inputs(st)
+    dinp = s.to_device(inp)
+    out = s.alloc_wbc_outputs(B)
+    gfix = hoqp.default_gait("crawl", fix_derivatives=1)
+
+    def cycle():
+        d = s.wbc_dynamics(dq, du)
+        lc, ct = s.gait_sample(gfix, time, vel, d["footpos"][:, :, :2].contiguous())
+        for k in ("M", "h", "Jfoot", "Jdotu", "footpos", "Jb"):
+            dinp[k] = d[k]
+        dinp["leg_cmd"], dinp["contact"] = lc, ct
+        s.solve_wbc(dinp, out)
+        s.wbc_poststep(2.5e-3, 40.0, 1.0, out["qdd"], out["tau"], qj, qdj, qc, qdc, tc)
+
+    ms = timed(cycle, max(5, args.steps // 5), warmup=2)
+    res["cycle N3 -> N1 -> solve -> N2 (crawl gait, reference semantics)"] = dict(
+        ms_per_launch=ms, states_per_s=B / (ms * 1e-3),
+        note="device-resident control cycle for a batch of states; the solve is %.0f %% of it" % 0.0)
+    ms_solve = timed(lambda: s.solve_wbc(dinp, out), max(5, args.steps // 5), warmup=2)
+    res["cycle N3 -> N1 -> solve -> N2 (crawl gait, reference semantics)"]["note"] = (
+        "device-resident control cycle for a batch of states; the solve alone takes %.3f ms (%.0f %% of it)"
+        % (ms_solve, 100.0 * ms_solve / ms))
     print(json.dumps(dict(batch=B, steps=args.steps, hbm_peak_gbs=HBM_PEAK_GBS, rows=res), indent=1))
 
 
