@@ -116,6 +116,46 @@ def test_wbc_full_size_properties(solver_factory):
     assert np.array_equal(out2["x"].cpu().numpy(), x)
 
 
+@pytest.mark.parametrize("mode", ["reference", "paper"])
+def test_wbc_trot_full_size(solver_factory, oracle, mode):
+    """configs[2] at full size (65,536 trot-mix states, 2- and 4-contact hierarchies in one launch):
+    size-independent properties on every instance, the oracle on a random subsample."""
+    B = 65536
+    s = solver_factory(mode)
+    inp = am.make_wbc_inputs(am.sample_states(B, 2345, "trot"))
+    out = s.solve_wbc(s.to_device(inp))
+    s.synchronize()
+    o = {k: v.cpu().numpy() for k, v in out.items()}
+    assert np.all(o["status"] == 0)
+    ct = inp["contact"].astype(bool)
+    assert set(np.unique(ct.sum(axis=1))) == {2, 4}
+    x = o["x"]
+    # contact forces in x follow the instance's own contact legs; scatter them to a [B, 4, 3] array
+    lam = np.zeros((B, 4, 3))
+    slot = np.cumsum(ct, axis=1) - 1
+    for leg in range(4):
+        on = ct[:, leg]
+        idx = 18 + 3 * slot[on, leg]
+        lam[on, leg] = np.stack([x[on, idx], x[on, idx + 1], x[on, idx + 2]], axis=1)
+    nc = ct.sum(axis=1)
+    assert np.all(x[nc == 2, 24:] == 0.0)   # zero padding beyond n = 18 + 3 n_c
+    M, h, Jf = inp["M"], inp["h"], inp["Jfoot"]
+    # level 0 (floating-base EoM): M_fb ud - sum_legs J_leg,fb' lam_leg = -h_fb, for every contact pattern
+    res = np.einsum("bij,bj->bi", M[:, :6, :], x[:, :18]) - np.einsum("blki,blk->bi", Jf[:, :, :, :6], lam) + h[:, :6]
+    assert np.abs(res).max() < 1e-7 * max(1.0, np.abs(h).max())
+    tau = np.einsum("bij,bj->bi", M[:, 6:, :], x[:, :18]) - np.einsum("blki,blk->bi", Jf[:, :, :, 6:], lam) + h[:, 6:]
+    assert np.abs(tau - o["tau"]).max() < 1e-9 * max(1.0, np.abs(tau).max())
+    assert np.all(o["flags"][:, 0] == 1)
+    assert np.array_equal(o["nz_levels"][:, 0], 12 + 3 * nc)
+    pick = np.random.default_rng(3).choice(B, 512, replace=False)
+    sub = {k: np.ascontiguousarray(v[pick]) for k, v in inp.items()}
+    ref, rc = oracle.wbc_solve_batch(sub, oracle.default_cfg(mode), oracle.default_wbc_params(mode), threads=8)
+    assert rc == 0
+    _close(x[pick], ref["x"], "x")
+    _close(o["tau"][pick], ref["tau"], "tau")
+    _close(o["v"][pick], ref["v"][:, :40], "v")
+
+
 def _random_hierarchy(rng, B, n, spec):
     tasks = []
     for (m, p) in spec:
