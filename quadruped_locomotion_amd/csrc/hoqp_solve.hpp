@@ -1761,12 +1761,21 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 			// rows [P, Pn) are broadcast from their lanes (no LDS round trip per row)
 			double dmine = -1.0;
 			{
-				double acc = q0 + q1 * tb;
-				for (int r = soft_lo; r < soft_hi; ++r) {
-					const double cr = readlane_d(ci, r), sr = readlane_d(si, r);
-					const double sv = fma(tb, cr, sr);
-					acc = (sv > 0.0 && r != lane) ? fma(cr, sv, acc) : acc;
+				// (the lane's own row contributes c (s + tb c) = 0 at its own breakpoint, so it needs no
+				// special case; max() instead of a select keeps the accumulation a plain FMA chain)
+				double acc = q0 + q1 * tb, acc1 = 0.0;
+				int r = soft_lo;
+				for (; r + 1 < soft_hi; r += 2) {
+					const double c0 = readlane_d(ci, r), s0 = readlane_d(si, r);
+					const double c1 = readlane_d(ci, r + 1), s1 = readlane_d(si, r + 1);
+					acc = fma(c0, fmax(fma(tb, c0, s0), 0.0), acc);
+					acc1 = fma(c1, fmax(fma(tb, c1, s1), 0.0), acc1);
 				}
+				if (r < soft_hi) {
+					const double c0 = readlane_d(ci, r), s0 = readlane_d(si, r);
+					acc = fma(c0, fmax(fma(tb, c0, s0), 0.0), acc);
+				}
+				acc += acc1;
 				dmine = (tb < 1e299) ? acc : -1.0;
 			}
 			const double t_hi = wave_min((tb < 1e299 && dmine >= 0.0) ? tb : 1e300);
