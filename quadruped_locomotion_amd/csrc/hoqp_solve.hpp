@@ -535,8 +535,9 @@ __device__ __forceinline__ void load_Urow(double (&Urow)[NR], int k1, int rb, co
 // L y = t  (inv = 1 / L(lane, lane), 0 for lanes >= rb); returns y_lane
 __device__ __forceinline__ double tri_fwd(const double (&Lrow)[NR], double inv, double t, int rb)
 {
-	const int lane = lane_id();
-	double acc = t, y = 0.0;
+	// Lrow[i] is zero for i >= lane, so a lane's accumulator is final after step lane - 1 and
+	// y_lane = acc * inv at the end (no per-step capture)
+	double acc = t;
 #pragma unroll
 	for (int b = 0; b < NR / 8; ++b) {
 		if (8 * b >= rb)
@@ -544,18 +545,16 @@ __device__ __forceinline__ double tri_fwd(const double (&Lrow)[NR], double inv, 
 #pragma unroll
 		for (int i = 8 * b; i < 8 * b + 8; ++i) {
 			const double yi = readlane_d(acc * inv, i);
-			y = (lane == i) ? yi : y;
 			acc = fma(-Lrow[i], yi, acc);
 		}
 	}
-	return y;
+	return acc * inv;
 }
 
 // U z = t; returns z_lane
 __device__ __forceinline__ double tri_bwd(const double (&Urow)[NR], double inv, double t, int rb)
 {
-	const int lane = lane_id();
-	double acc = t, z = 0.0;
+	double acc = t;  // Urow[i] is zero for i <= lane: z_lane = acc * inv at the end
 #pragma unroll
 	for (int b = NR / 8 - 1; b >= 0; --b) {
 		if (8 * b >= rb)
@@ -563,11 +562,10 @@ __device__ __forceinline__ double tri_bwd(const double (&Urow)[NR], double inv, 
 #pragma unroll
 		for (int i = 8 * b + 7; i >= 8 * b; --i) {
 			const double zi = readlane_d(acc * inv, i);
-			z = (lane == i) ? zi : z;
 			acc = fma(-Urow[i], zi, acc);
 		}
 	}
-	return z;
+	return acc * inv;
 }
 
 // Solves the (<= 8 x 8) symmetric positive definite system M a = g by Gauss-Jordan without
