@@ -614,12 +614,17 @@ __device__ __forceinline__ double ls_solve_reg(int k1, int k2, int qB0, int qB1,
 	const bool act = lane < rb;
 	const int pl = l.pivlane[k1 + (act ? lane : 0)];
 	const double rp = sel(act, l.rhs[pl]);  // rhs by pivot position
-	const double inv = sel(act, fast_rcp(l.rdiag[k1 + (act ? lane : 0)]));
+	const double rdg = l.rdiag[k1 + (act ? lane : 0)];
+	const double inv = sel(act, fast_rcp(rdg));
 	if (nunp == 0) {
 		double Lrow[NR];
 		load_Lrow(Lrow, k1, rb, l);
 		double q = tri_fwd(Lrow, inv, rp, rb);
-		if (eps != 0.0) {
+		// The eps term moves q by about eps / sigma_min(R)^2 relative; with the smallest pivot as
+		// the estimate of sigma_min the two extra triangular solves are skipped while that is
+		// below 1e-10 (tolerance of the whole path: 1e-6).
+		const double dmin = wave_min(act ? fabs(rdg) : 1e300);
+		if (eps != 0.0 && eps > 1e-10 * dmin * dmin) {
 			double Urow[NR];
 			load_Urow(Urow, k1, rb, l);
 			const double z = tri_bwd(Urow, inv, q, rb);  // U z = q
@@ -1433,7 +1438,8 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 				double Urow[NR];
 				load_Urow(Urow, 0, nz, l);
 				double z = tri_bwd(Urow, inv, sel(act, cl), nz);
-				if (a.eps != 0.0) {
+				const double dmin = wave_min(act ? fabs(l.rdiag[lane]) : 1e300);
+				if (a.eps != 0.0 && a.eps > 1e-10 * dmin * dmin) {  // see ls_solve_reg
 					double Lrow[NR];
 					load_Lrow(Lrow, 0, nz, l);
 					const double wv = tri_fwd(Lrow, inv, z, nz);
