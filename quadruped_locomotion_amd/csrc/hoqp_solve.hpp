@@ -1916,9 +1916,19 @@ __global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
 	st.t_last = __builtin_amdgcn_s_memtime();
 	const int n = st.n, ld = a.ld;
 	// InitPrevProblemValuesToDefault, ho_qp_problem.cpp:119-128:  Z = I, x = 0
-	for (int idx = lane; idx < n * ld; idx += kWave) {
-		int r = idx / ld, c = idx - r * ld;
-		l.Z[idx] = (r == c) ? 1.0 : 0.0;
+	{
+		// (row, column) of entry idx advance by 64 entries per trip without a division per trip
+		const int qstep = kWave / ld, rstep = kWave - qstep * ld;
+		int r = lane / ld, c = lane - r * ld;
+		for (int idx = lane; idx < n * ld; idx += kWave) {
+			l.Z[idx] = (r == c) ? 1.0 : 0.0;
+			r += qstep;
+			c += rstep;
+			if (c >= ld) {
+				c -= ld;
+				++r;
+			}
+		}
 	}
 	if (lane < NR)
 		l.x[lane] = 0.0;
