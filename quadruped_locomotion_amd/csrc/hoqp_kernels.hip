@@ -41,32 +41,46 @@ struct WbcArgs {
 
 constexpr int kNU = 18, kNJ = 12, kNB = 6, kNX = 30;
 
-// Fill `count` consecutive doubles (one per lane and pass): every value of the block is computed
-// first (the gathers from M / J are independent and stay in flight together), then stored.  The
-// task arrays and the inputs are reached through struct members, so without the split the
-// compiler has to keep each store ahead of the next pass's loads.
+// threads per instance in wbc_build_kernel (four wavefronts per instance were measured no faster: the
+// kernel is bound by the 89 MB it writes per 4096 states, not by latency)
+constexpr int kBuildThreads = 64;
+
+// One entry of a task block: either a constant or +-(a value loaded from the inputs).
+struct Entry {
+	const double *p;  // always a readable address (the load is issued unconditionally)
+	double scale;	  // 0: the entry is the constant `add`
+	double add;
+};
+
+// Fill COUNT consecutive doubles (one per lane and pass).  Every pass's source address is computed
+// first and ALL loads of the block are issued back to back (a load behind a condition costs a
+// branch and a wait per pass: the gathers from M / J then serialise on the L2 latency), then the
+// values are formed and stored.
 template <int COUNT, typename F>
-__device__ __forceinline__ void fill_block(double *dst, F value)
+__device__ __forceinline__ void fill_block(double *dst, F entry)
 {
-	constexpr int PASSES = (COUNT + kWave - 1) / kWave;
-	const int lane = lane_id();
-	double v[PASSES];
+	constexpr int PASSES = (COUNT + kBuildThreads - 1) / kBuildThreads;
+	const int lane = threadIdx.x;
+	double v[PASSES], sc[PASSES], ad[PASSES];
 #pragma unroll
 	for (int it = 0; it < PASSES; ++it) {
-		const int idx = lane + kWave * it;
-		v[it] = value(idx < COUNT ? idx : COUNT - 1);
+		const int idx = lane + kBuildThreads * it;
+		const Entry e = entry(idx < COUNT ? idx : COUNT - 1);
+		v[it] = *e.p;
+		sc[it] = e.scale;
+		ad[it] = e.add;
 	}
 #pragma unroll
 	for (int it = 0; it < PASSES; ++it) {
-		const int idx = lane + kWave * it;
+		const int idx = lane + kBuildThreads * it;
 		if (idx < COUNT)
-			dst[idx] = v[it];
+			dst[idx] = (sc[it] != 0.0) ? sc[it] * v[it] : ad[it];
 	}
 }
 
-__global__ void __launch_bounds__(kWave) wbc_build_kernel(const WbcArgs a)
+__global__ void __launch_bounds__(kBuildThreads) wbc_build_kernel(const WbcArgs a)
 {
-	const int lane = lane_id();
+	const int lane = threadIdx.x;
 	const int inst = blockIdx.x;
 	if (inst >= a.in.batch)
 		return;
@@ -94,9 +108,14 @@ __global__ void __launch_bounds__(kWave) wbc_build_kernel(const WbcArgs a)
 	for (int g = ns; g < 4; ++g)
 		sl[g] = 0;
 	const int n = kNU + 3 * nc;  // :64
-	auto JC = [&](int i, int c) { return Jf[(cl[i / 3] * 3 + i % 3) * kNU + c]; };
-	auto JS = [&](int i, int c) { return Jf[(sl[i / 3] * 3 + i % 3) * kNU + c]; };
-	auto JB = [&](int r, int c) { return Jb ? Jb[r * kNU + c] : (r == c ? 1.0 : 0.0); };
+	// i-th contact / swing leg without indexing a local array by a run-time value
+	auto pick = [](const int (&v)[4], int i) { return i == 0 ? v[0] : (i == 1 ? v[1] : (i == 2 ? v[2] : v[3])); };
+	// row i (3 per leg) of the stacked contact / swing Jacobian, column c: address in Jfoot
+	auto JCp = [&](int i, int c) { return Jf + (pick(cl, (i / 3) & 3) * 3 + i % 3) * kNU + c; };
+	auto JSp = [&](int i, int c) { return Jf + (pick(sl, (i / 3) & 3) * 3 + i % 3) * kNU + c; };
+	auto JC = [&](int i, int c) { return *JCp(i, c); };
+	auto JS = [&](int i, int c) { return *JSp(i, c); };
+	const Entry zero = {M, 0.0, 0.0};
 
 	if (lane == 0) {
 		a.n_inst[inst] = n;
@@ -114,13 +133,13 @@ __global__ void __launch_bounds__(kWave) wbc_build_kernel(const WbcArgs a)
 	{
 		double *A = a.A0 + (size_t)inst * kNB * kNX;
 		fill_block<kNB * kNX>(A, [&](int idx) {
-			int r = idx / kNX, c = idx - r * kNX;
-			double v = 0.0;
+			const int r = idx / kNX, c = idx - r * kNX;
+			Entry e = zero;
 			if (c < kNU)
-				v = M[r * kNU + c];
+				e = {M + r * kNU + c, 1.0, 0.0};
 			else if (c < n)
-				v = -JC(c - kNU, r);
-			return v;
+				e = {JCp(c - kNU, r), -1.0, 0.0};
+			return e;
 		});
 		if (lane < kNB)
 			a.b0[(size_t)inst * kNB + lane] = -h[lane];
@@ -130,27 +149,27 @@ __global__ void __launch_bounds__(kWave) wbc_build_kernel(const WbcArgs a)
 		double *D = a.D1 + (size_t)inst * 40 * kNX;
 		double *f = a.f1 + (size_t)inst * 40;
 		fill_block<40 * kNX>(D, [&](int idx) {
-			int r = idx / kNX, c = idx - r * kNX;
-			double v = 0.0;
+			const int r = idx / kNX, c = idx - r * kNX;
+			Entry e = zero;
 			if (r < 2 * kNJ) {
-				int rr = (r < kNJ) ? r : r - kNJ;
-				double sg = (r < kNJ) ? 1.0 : -1.0;
+				const int rr = (r < kNJ) ? r : r - kNJ;
+				const double sg = (r < kNJ) ? 1.0 : -1.0;
 				if (c < kNU)
-					v = sg * M[(kNB + rr) * kNU + c];
+					e = {M + (kNB + rr) * kNU + c, sg, 0.0};
 				else if (c < n)
-					v = -sg * JC(c - kNU, kNB + rr);
+					e = {JCp(c - kNU, kNB + rr), -sg, 0.0};
 			} else if (r < 2 * kNJ + 4 * nc) {
-				int i = (r - 2 * kNJ) / 4, t = (r - 2 * kNJ) % 4;
-				int col = a.friction_quirk ? kNB + cl[i] * 3 : kNU + 3 * i;
-				int d = c - col;
+				const int i = (r - 2 * kNJ) / 4, t = (r - 2 * kNJ) % 4;
+				const int col = a.friction_quirk ? kNB + pick(cl, i) * 3 : kNU + 3 * i;
+				const int d = c - col;
 				if (d == 2)
-					v = -a.mu;
+					e.add = -a.mu;
 				else if (d == 0 && t < 2)
-					v = (t == 0) ? 1.0 : -1.0;
+					e.add = (t == 0) ? 1.0 : -1.0;
 				else if (d == 1 && t >= 2)
-					v = (t == 2) ? 1.0 : -1.0;
+					e.add = (t == 2) ? 1.0 : -1.0;
 			}
-			return v;
+			return e;
 		});
 		if (lane < 40) {
 			double v = 0.0;
@@ -165,27 +184,33 @@ __global__ void __launch_bounds__(kWave) wbc_build_kernel(const WbcArgs a)
 	{
 		double *A = a.A2 + (size_t)inst * 12 * kNX;
 		fill_block<12 * kNX>(A, [&](int idx) {
-			int r = idx / kNX, c = idx - r * kNX;
-			return (r < 3 * nc && c < kNU) ? JC(r, c) : 0.0;
+			const int r = idx / kNX, c = idx - r * kNX;
+			Entry e = zero;
+			if (r < 3 * nc && c < kNU)
+				e = {JCp(r, c), 1.0, 0.0};
+			return e;
 		});
 		if (lane < 12)
-			a.b2[(size_t)inst * 12 + lane] = (lane < 3 * nc) ? -Jdu[cl[lane / 3] * 3 + lane % 3] : 0.0;
+			a.b2[(size_t)inst * 12 + lane] = (lane < 3 * nc) ? -Jdu[pick(cl, lane / 3) * 3 + lane % 3] : 0.0;
 	}
 	// level 3: base pos :217-247, base rot :249-281, swing legs :186-215
 	{
 		double *A = a.A3 + (size_t)inst * 18 * kNX;
 		fill_block<18 * kNX>(A, [&](int idx) {
-			int r = idx / kNX, c = idx - r * kNX;
-			double v = 0.0;
+			const int r = idx / kNX, c = idx - r * kNX;
+			Entry e = zero;
 			if (c < kNU) {
-				if (r < 3)
-					v = JB(3 + r, c);
-				else if (r < 6)
-					v = JB(r - 3, c);
-				else if (r < 6 + 3 * ns)
-					v = JS(r - 6, c);
+				if (r < 6) {
+					const int rb = (r < 3) ? 3 + r : r - 3;
+					if (Jb)
+						e = {Jb + rb * kNU + c, 1.0, 0.0};
+					else
+						e.add = (rb == c) ? 1.0 : 0.0;
+				} else if (r < 6 + 3 * ns) {
+					e = {JSp(r - 6, c), 1.0, 0.0};
+				}
 			}
-			return v;
+			return e;
 		});
 		if (lane < 18) {
 			double v = 0.0;
@@ -200,7 +225,7 @@ __global__ void __launch_bounds__(kWave) wbc_build_kernel(const WbcArgs a)
 				double vel = 0.0;
 				for (int c = 0; c < kNU; ++c)
 					vel = fma(JS(i, c), u[c], vel);
-				int li = sl[i / 3] * 3 + i % 3;
+				int li = pick(sl, i / 3) * 3 + i % 3;
 				v = lc[24 + li] + a.kp_swing * (lc[li] - fp[li]) + a.kv_swing * (lc[12 + li] - vel);
 			}
 			a.b3[(size_t)inst * 18 + lane] = v;
@@ -210,8 +235,10 @@ __global__ void __launch_bounds__(kWave) wbc_build_kernel(const WbcArgs a)
 	{
 		double *A = a.A4 + (size_t)inst * 12 * kNX;
 		fill_block<12 * kNX>(A, [&](int idx) {
-			int r = idx / kNX, c = idx - r * kNX;
-			return (r < 3 * nc && c == kNU + r) ? 1.0 : 0.0;
+			const int r = idx / kNX, c = idx - r * kNX;
+			Entry e = zero;
+			e.add = (r < 3 * nc && c == kNU + r) ? 1.0 : 0.0;
+			return e;
 		});
 		if (lane < 12)
 			a.b4[(size_t)inst * 12 + lane] = 0.0;
@@ -628,7 +655,7 @@ extern "C" int hoqp_solve_wbc_batched(hoqp_handle *h, const hoqp_wbc_inputs *in,
 	w.n_inst = h->ws_i;
 	w.m_inst = h->ws_i + B;
 	w.p_inst = h->ws_i + (size_t)6 * B;
-	hipLaunchKernelGGL(wbc_build_kernel, dim3(B), dim3(kWave), 0, s, w);
+	hipLaunchKernelGGL(wbc_build_kernel, dim3(B), dim3(kBuildThreads), 0, s, w);
 	HIP_OK(h, hipGetLastError());
 
 	hoqp_task_batch t;
