@@ -56,8 +56,10 @@ struct Entry {
 // first and ALL loads of the block are issued back to back (a load behind a condition costs a
 // branch and a wait per pass: the gathers from M / J then serialise on the L2 latency), then the
 // values are formed and stored.
+// Only the first `used` entries are stored: rows beyond an instance's own row count are never read
+// by the solve (it takes m_inst / p_inst rows), so they are not written either.
 template <int COUNT, typename F>
-__device__ __forceinline__ void fill_block(double *dst, F entry)
+__device__ __forceinline__ void fill_block(double *dst, int used, F entry)
 {
 	constexpr int PASSES = (COUNT + kBuildThreads - 1) / kBuildThreads;
 	const int lane = threadIdx.x;
@@ -73,7 +75,7 @@ __device__ __forceinline__ void fill_block(double *dst, F entry)
 #pragma unroll
 	for (int it = 0; it < PASSES; ++it) {
 		const int idx = lane + kBuildThreads * it;
-		if (idx < COUNT)
+		if (idx < used)
 			dst[idx] = (sc[it] != 0.0) ? sc[it] * v[it] : ad[it];
 	}
 }
@@ -132,7 +134,7 @@ __global__ void __launch_bounds__(kBuildThreads) wbc_build_kernel(const WbcArgs 
 	// level 0: ConstructFloatingBaseEomTask, :351-366
 	{
 		double *A = a.A0 + (size_t)inst * kNB * kNX;
-		fill_block<kNB * kNX>(A, [&](int idx) {
+		fill_block<kNB * kNX>(A, kNB * kNX, [&](int idx) {
 			const int r = idx / kNX, c = idx - r * kNX;
 			Entry e = zero;
 			if (c < kNU)
@@ -148,7 +150,7 @@ __global__ void __launch_bounds__(kBuildThreads) wbc_build_kernel(const WbcArgs 
 	{
 		double *D = a.D1 + (size_t)inst * 40 * kNX;
 		double *f = a.f1 + (size_t)inst * 40;
-		fill_block<40 * kNX>(D, [&](int idx) {
+		fill_block<40 * kNX>(D, (2 * kNJ + 4 * nc) * kNX, [&](int idx) {
 			const int r = idx / kNX, c = idx - r * kNX;
 			Entry e = zero;
 			if (r < 2 * kNJ) {
@@ -183,7 +185,7 @@ __global__ void __launch_bounds__(kBuildThreads) wbc_build_kernel(const WbcArgs 
 	// level 2: ConstructNoContactMotionTask, :283-297
 	{
 		double *A = a.A2 + (size_t)inst * 12 * kNX;
-		fill_block<12 * kNX>(A, [&](int idx) {
+		fill_block<12 * kNX>(A, 3 * nc * kNX, [&](int idx) {
 			const int r = idx / kNX, c = idx - r * kNX;
 			Entry e = zero;
 			if (r < 3 * nc && c < kNU)
@@ -196,7 +198,7 @@ __global__ void __launch_bounds__(kBuildThreads) wbc_build_kernel(const WbcArgs 
 	// level 3: base pos :217-247, base rot :249-281, swing legs :186-215
 	{
 		double *A = a.A3 + (size_t)inst * 18 * kNX;
-		fill_block<18 * kNX>(A, [&](int idx) {
+		fill_block<18 * kNX>(A, (6 + 3 * ns) * kNX, [&](int idx) {
 			const int r = idx / kNX, c = idx - r * kNX;
 			Entry e = zero;
 			if (c < kNU) {
@@ -234,7 +236,7 @@ __global__ void __launch_bounds__(kBuildThreads) wbc_build_kernel(const WbcArgs 
 	// level 4: ConstructForceMinimizationTask, :385-400
 	{
 		double *A = a.A4 + (size_t)inst * 12 * kNX;
-		fill_block<12 * kNX>(A, [&](int idx) {
+		fill_block<12 * kNX>(A, 3 * nc * kNX, [&](int idx) {
 			const int r = idx / kNX, c = idx - r * kNX;
 			Entry e = zero;
 			e.add = (r < 3 * nc && c == kNU + r) ? 1.0 : 0.0;
