@@ -21,10 +21,10 @@ constexpr int NT = NR / 4; // entries of one vector held by one lane
 constexpr int NSP = 4;	  // panel slots: 64 columns  (working set + LS rows + violated rows)
 constexpr int NSR = 6;	  // row slots: 96 rows >= HOQP_MAX_VARS + HOQP_MAX_INEQ_ROWS
 constexpr int LDV = 34;	  // leading dimension of the reflector store
-constexpr int SROW = 36;  // row stride of the task staging buffer (16-byte aligned rows; 36 keeps the
-			  // 16-rows-by-4-columns MFMA operand read at a 2-way bank conflict, 32 would be 16-way)
+constexpr int SROW = 36;  // row stride of the task staging buffer of the n_z == 32 projection (16-byte
+			  // aligned rows); the matrix-core projection loads its operand from global memory
 constexpr int XROWS = 16; // dumped unpivoted columns (rank-deficient least squares); aliases S
-constexpr int CHUNK = 16; // task rows staged per pass
+constexpr int CHUNK = 16; // task rows per projection pass (one 16 x K matrix-core operand tile)
 
 static_assert(NR >= HOQP_MAX_VARS, "register tiles must cover n");
 static_assert(16 * NSR >= HOQP_MAX_VARS + HOQP_MAX_INEQ_ROWS, "row slots must cover Z and G");
@@ -930,7 +930,7 @@ __device__ __forceinline__ void project_task(const double *__restrict__ rows_g, 
 }
 
 // ---------------------------------------------------------------------------
-// Task projection on the matrix cores (n_z <= 31).  A chunk of 16 staged task rows is one
+// Task projection on the matrix cores (n_z <= 31).  A chunk of 16 task rows is one
 // 16 x K operand tile of v_mfma_f64_16x16x4_f64; [Z | x] (n x (n_z + 1)) is the other operand,
 // kept in registers for the whole level:  bm[kb][cb] = B[k = 4 kb + lane/16][j = 16 cb + lane%16]
 // with B[k][j] = Z[k][j] (j < n_z), x[k] (j == n_z), 0 otherwise / for k >= n.
