@@ -46,8 +46,9 @@ extern "C" {
 #define HOQP_STATUS_MAX_ITER 0x01	 /* active-set iteration cap hit at some level (iterate is feasible) */
 #define HOQP_STATUS_INFEASIBLE_START 0x02 /* a prior (hard) row was violated when a level started */
 #define HOQP_STATUS_WORKSPACE 0x04	 /* working set outgrew the LDS workspace */
-#define HOQP_STATUS_NONFINITE 0x08	 /* NaN/Inf in the inputs or the solution */
+#define HOQP_STATUS_NONFINITE 0x08	 /* NaN/Inf in the final x, a slack, a level residual, a validity residual or tau */
 #define HOQP_STATUS_UNSUPPORTED 0x10	 /* (unused since Q3 is reproduced for any number of inequality levels) */
+#define HOQP_STATUS_BAD_EXTENT 0x20	 /* n_inst / m_inst / p_inst beyond the storage extent: clamped to it */
 
 typedef struct hoqp_handle hoqp_handle;
 
@@ -66,9 +67,11 @@ typedef struct {
 void hoqp_default_config(hoqp_config *cfg);
 
 /* Replaces: HoQpController::HoQpController (ho_qp_controller.cpp:5).  One handle per host
- * thread and GPU; handles share no mutable state.  A handle owns the task workspace of
- * hoqp_solve_wbc_batched, so calls on ONE handle must be issued to one stream at a time
- * (use a handle per stream to overlap launches). */
+ * thread and GPU; handles share no mutable state.  hoqp_solve_wbc_batched and hoqp_solve_tasks_batched keep no state in the
+ * handle and may be issued to any number of streams; the host-buffer entries and
+ * hoqp_solve_wbc_unfused use handle-owned staging and must be issued one at a time per handle.
+ * Every entry point makes the handle's device current for its own duration and restores the
+ * caller's current device before it returns. */
 int hoqp_create(const hoqp_config *cfg, hoqp_handle **out);
 int hoqp_destroy(hoqp_handle *h);
 const char *hoqp_last_error_string(const hoqp_handle *h);
@@ -149,6 +152,24 @@ typedef struct {
  * CalcJointTorquesCmd (:67-73).  Mixed contact patterns are handled per instance.
  */
 int hoqp_solve_wbc_batched(hoqp_handle *h, const hoqp_wbc_inputs *in, const hoqp_wbc_outputs *out, void *stream);
+
+/*
+ * Replaces: the same span of HoQpController::CalcJointCmd as hoqp_solve_wbc_batched, as three
+ * kernels instead of one: ConstructTasks (ho_qp_controller.cpp:147-184) materialised as dense task
+ * blocks in a handle-owned, grow-only workspace, the generic level chain on them
+ * (ConstructOptProblems, :120-141), then CalcJointTorquesCmd (:67-73).  Same results; kept as the
+ * cross-check of the fused kernel.  One stream at a time per handle (the workspace is shared).
+ */
+int hoqp_solve_wbc_unfused(hoqp_handle *h, const hoqp_wbc_inputs *in, const hoqp_wbc_outputs *out, void *stream);
+
+/*
+ * Replaces: HoQpController::ConstructTasks (ho_qp_controller.cpp:147-184) alone -- the five
+ * TaskDefinitions of every instance written to caller-owned device storage `tasks` (a
+ * hoqp_task_batch with n = 30, num_levels = 5, m = {6,0,12,18,12}, p = {0,40,0,0,0}, A[0], b[0], D[1],
+ * f[1], A[2..4], b[2..4] and n_inst / m_inst / p_inst all non-NULL and writable).  Rows beyond an
+ * instance's own count are zeroed.  The result can be handed to hoqp_solve_tasks_batched as is.
+ */
+int hoqp_wbc_build_tasks_batched(hoqp_handle *h, const hoqp_wbc_inputs *in, const hoqp_task_batch *tasks, void *stream);
 
 /*
  * Host-buffer variants: every pointer in the structs is a HOST pointer; the library stages

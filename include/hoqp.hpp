@@ -203,9 +203,12 @@ inline TaskDefinition ConcatenateTasks(const std::vector<TaskDefinition> &tasks)
 namespace control {
 
 // ---------------------------------------------------------------------------
-// ho_qp_problem.hpp:20-43.  As in the reference the solve happens in the constructor.
-// A level re-solves its whole ancestor chain in ONE kernel launch (the chain state never
-// leaves LDS), so constructing level k costs one launch, not k.
+// ho_qp_problem.hpp:20-43.  The reference solves in the constructor; here a level solves its whole
+// ancestor chain in ONE kernel launch (the chain state never leaves LDS) the first time one of its
+// results is asked for.  HoQpController::ConstructOptProblems (ho_qp_controller.cpp:120-141) builds
+// the chain of five and only reads the last problem (:17), so the cycle costs one upload and one
+// launch instead of five of each (an eager solve per constructor would redo every ancestor:
+// O(L^2) work).  Getters of an intermediate level still work: they solve that level's own chain.
 // ---------------------------------------------------------------------------
 class HoQpProblem {
 public:
@@ -217,7 +220,8 @@ public:
 		if (higher_pri_problem_)
 			chain_ = higher_pri_problem_->chain_;
 		chain_.push_back(curr_task_);
-		Solve();
+		if ((int)chain_.size() > HOQP_MAX_LEVELS)
+			throw std::runtime_error("HoQpProblem: more than HOQP_MAX_LEVELS levels");
 	}
 
 	TaskDefinition GetStackedTasks()
@@ -228,14 +232,29 @@ public:
 			st = ConcatenateTasks(st, chain_[k]);
 		return st;
 	}
-	hoqp::MatrixXd GetStackedNullspaceMatrix() { return stacked_Z_; }
-	int GetStackedNumSlackVars() { return num_stacked_slack_; }
-	hoqp::VectorXd GetSolution() { return x_; }
-	hoqp::VectorXd GetSlackSolutions() { return slack_; }
-	hoqp::VectorXd GetStackedSlackSolutions() { return stacked_slack_; }
-	int GetStatus() const { return status_; }
+	hoqp::MatrixXd GetStackedNullspaceMatrix() { return Solved().stacked_Z_; }
+	int GetStackedNumSlackVars()
+	{
+		int P = 0;  // known without solving
+		for (auto &t : chain_)
+			P += (int)t.D.rows();
+		return P;
+	}
+	hoqp::VectorXd GetSolution() { return Solved().x_; }
+	hoqp::VectorXd GetSlackSolutions() { return Solved().slack_; }
+	hoqp::VectorXd GetStackedSlackSolutions() { return Solved().stacked_slack_; }
+	int GetStatus() { return Solved().status_; }
 
 private:
+	HoQpProblem &Solved()
+	{
+		if (!solved_) {
+			Solve();
+			solved_ = true;
+		}
+		return *this;
+	}
+
 	void Solve()
 	{
 		auto hd = hoqp::thread_handle();
@@ -307,6 +326,7 @@ private:
 	hoqp::MatrixXd stacked_Z_;
 	int num_stacked_slack_ = 0;
 	int status_ = 0;
+	bool solved_ = false;
 };
 
 // ---------------------------------------------------------------------------
@@ -362,10 +382,16 @@ public:
 	// Instead of SetModelDynamics: let CalcJointCmd produce M, h, J, ... from (q, u) itself, as
 	// the reference's UpdateModelDynamics does (ho_qp_controller.cpp:89-114), with the library's
 	// quadruped model (hoqp_wbc_dynamics_host; model == nullptr: the default parameters).
-	void UseBuiltinDynamics(const hoqp_quadruped_model *model = nullptr, bool include_gravity = true)
+	// include_gravity < 0 (default): follow the handle's semantics -- under HOQP_SEMANTICS_REFERENCE
+	// h is the reference's CalcBiasTerm, which carries NO gravity (dynamics.cpp:82-87); under any other
+	// semantics gravity is part of h.  0 / 1 force it off / on.
+	void UseBuiltinDynamics(const hoqp_quadruped_model *model = nullptr, int include_gravity = -1)
 	{
 		builtin_ = true;
-		include_gravity_ = include_gravity;
+		if (include_gravity < 0)
+			include_gravity_ = hoqp::thread_handle()->cfg.semantics != HOQP_SEMANTICS_REFERENCE;
+		else
+			include_gravity_ = include_gravity != 0;
 		if (model)
 			model_ = *model;
 		else

@@ -1122,10 +1122,13 @@ void hoqp_oracle_gait_sample(int N, int n_steps, double duration, const int *sch
 {
 	const double step_time = duration / (double)n_steps;
 	for (int i = 0; i < N; ++i) {
-		const double t_rel = fmod(time[i], duration);
+		/* negative times (never produced by the reference's ros::Time differences) count as 0 */
+		const double t_rel = fmax(0.0, fmod(time[i], duration));
 		int step = (int)(t_rel / step_time);
 		if (step > n_steps - 1)
 			step = n_steps - 1;
+		if (step < 0)
+			step = 0;
 		for (int leg = 0; leg < 4; ++leg) {
 			const int *sch = schedule + leg * n_steps;
 			double pos[2] = {stance0[(i * 4 + leg) * 2], stance0[(i * 4 + leg) * 2 + 1]};
@@ -1189,7 +1192,7 @@ void hoqp_oracle_standup_sample(int N, double seconds, double target_height, con
 	for (int i = 0; i < N; ++i) {
 		const double *c = curr_pose + i * 3;
 		const double tgt[3] = {c[0], c[1], target_height};
-		const double t = time[i];
+		const double t = fmax(time[i], 0.0); /* Drake's FirstOrderHold::value clamps to the first break */
 		for (int d = 0; d < 3; ++d) {
 			const double slope = (tgt[d] - c[d]) / seconds;
 			base_cmd[i * 9 + d] = (t > seconds) ? tgt[d] : c[d] + slope * t;

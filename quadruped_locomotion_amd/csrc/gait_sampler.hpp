@@ -19,9 +19,11 @@ __global__ void gait_sample_kernel(hoqp_gait g, int batch, const double *__restr
 	if (i >= batch)
 		return;
 	const double step_time = g.duration / (double)g.n_steps;
-	const double t_rel = fmod(time[i], g.duration);
+	// time is device data: a negative time (the reference's ros::Time differences never are) is taken
+	// as 0 instead of giving a negative gait step (a shift by a negative count below)
+	const double t_rel = fmax(0.0, fmod(time[i], g.duration));
 	int step = (int)(t_rel / step_time);  // GetGaitStepFromTime, leg_planner.cpp:393-399
-	step = step > g.n_steps - 1 ? g.n_steps - 1 : step;
+	step = step > g.n_steps - 1 ? g.n_steps - 1 : (step < 0 ? 0 : step);
 	const unsigned bits = g.contact_bits[leg];
 	const double vx = vel_cmd[2 * i] * step_time, vy = vel_cmd[2 * i + 1] * step_time;
 	double px = stance0[(4 * i + leg) * 2], py = stance0[(4 * i + leg) * 2 + 1];
@@ -81,7 +83,7 @@ __global__ void standup_sample_kernel(int batch, double seconds, double target_h
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= batch)
 		return;
-	const double t = time[i];
+	const double t = fmax(time[i], 0.0);  // Drake's FirstOrderHold::value clamps to the first break
 	for (int d = 0; d < 3; ++d) {
 		const double c = curr_pose[3 * i + d];
 		const double tgt = (d == 2) ? target_height : c;

@@ -21,6 +21,7 @@
 
 #include "../../include/hoqp.h"
 #include "hoqp_device.hpp"
+#include "wbc_tasks.hpp"
 #include "hoqp_solve.hpp"
 #include "wbc_dynamics.hpp"
 #include "gait_sampler.hpp"
@@ -28,29 +29,22 @@
 namespace hoqp {
 
 // ---------------------------------------------------------------------------
-// WBC task construction (HoQpController::ConstructTasks, ho_qp_controller.cpp:147-184)
+// WBC task construction as dense blocks (HoQpController::ConstructTasks,
+// ho_qp_controller.cpp:147-184): the task-dump entry and the allocation-free entry.  The fused
+// entry never materialises the blocks; both use the generator of wbc_tasks.hpp.
 // ---------------------------------------------------------------------------
 struct WbcArgs {
 	hoqp_wbc_inputs in;
-	int friction_quirk, drop_base_gain;
-	double mu, tau_max, tau_min, kp_swing, kv_swing, kp_base, kv_base, kv_rot;
-	// task storage (handle workspace), extents of hoqp_wbc_extents()
+	WbcPrm prm;
+	int write_all;  // also zero the rows beyond an instance's own row count
+	// task storage, extents kWbcMmax / kWbcPmax
 	double *A0, *b0, *D1, *f1, *A2, *b2, *A3, *b3, *A4, *b4;
 	int *n_inst, *m_inst, *p_inst;
 };
 
-constexpr int kNU = 18, kNJ = 12, kNB = 6, kNX = 30;
-
 // threads per instance in wbc_build_kernel (four wavefronts per instance were measured no faster: the
 // kernel is bound by the 89 MB it writes per 4096 states, not by latency)
 constexpr int kBuildThreads = 64;
-
-// One entry of a task block: either a constant or +-(a value loaded from the inputs).
-struct Entry {
-	const double *p;  // always a readable address (the load is issued unconditionally)
-	double scale;	  // 0: the entry is the constant `add`
-	double add;
-};
 
 // Fill COUNT consecutive doubles (one per lane and pass).  Every pass's source address is computed
 // first and ALL loads of the block are issued back to back (a load behind a condition costs a
@@ -80,175 +74,56 @@ __device__ __forceinline__ void fill_block(double *dst, int used, F entry)
 	}
 }
 
+template <int LEVEL, int ROWS>
+__device__ __forceinline__ void build_level(const WbcCtx &x, const WbcPrm &prm, double *blk, double *rhs, int rows, bool all)
+{
+	const int lane = threadIdx.x;
+	fill_block<ROWS * kNX>(blk, (all ? ROWS : rows) * kNX, [&](int idx) {
+		const int r = idx / kNX, c = idx - r * kNX;
+		Entry e = wbc_entry<LEVEL>(x, prm, r, c, wbc_jcoff(x, c));
+		if (r >= rows)
+			e = {x.M, 0.0, 0.0};
+		return e;
+	});
+	if (lane < (all ? ROWS : rows)) {
+		double v = 0.0;
+		if (lane < rows) {
+			if (LEVEL == 3) {
+				v = wbc_rhs3(x, prm, lane);
+			} else {
+				const Entry e = wbc_rhs_entry<LEVEL>(x, prm, lane);
+				v = rhs_value(e, *e.p);
+			}
+		}
+		rhs[lane] = v;
+	}
+}
+
 __global__ void __launch_bounds__(kBuildThreads) wbc_build_kernel(const WbcArgs a)
 {
 	const int lane = threadIdx.x;
 	const int inst = blockIdx.x;
 	if (inst >= a.in.batch)
 		return;
-	const double *M = a.in.M + (size_t)inst * kNU * kNU;
-	const double *h = a.in.h + (size_t)inst * kNU;
-	const double *Jf = a.in.Jfoot + (size_t)inst * 12 * kNU;
-	const double *Jdu = a.in.Jdotu + (size_t)inst * 12;
-	const double *fp = a.in.footpos + (size_t)inst * 12;
-	const double *Jb = a.in.Jb ? a.in.Jb + (size_t)inst * 6 * kNU : nullptr;
-	const double *q = a.in.q + (size_t)inst * 19;
-	const double *u = a.in.u + (size_t)inst * kNU;
-	const double *bc = a.in.base_cmd + (size_t)inst * 9;
-	const double *lc = a.in.leg_cmd + (size_t)inst * 36;
-	const int *ct = a.in.contact + (size_t)inst * 4;
-	// GetContactLegs / GetSwingLegs, ho_qp_controller.cpp:426-450
-	int cl[4], sl[4], nc = 0, ns = 0;
-	for (int g = 0; g < 4; ++g) {
-		if (ct[g] == 1)
-			cl[nc++] = g;
-		if (ct[g] == 0)
-			sl[ns++] = g;
-	}
-	for (int g = nc; g < 4; ++g)
-		cl[g] = 0;
-	for (int g = ns; g < 4; ++g)
-		sl[g] = 0;
-	const int n = kNU + 3 * nc;  // :64
-	// i-th contact / swing leg without indexing a local array by a run-time value
-	auto pick = [](const int (&v)[4], int i) { return i == 0 ? v[0] : (i == 1 ? v[1] : (i == 2 ? v[2] : v[3])); };
-	// row i (3 per leg) of the stacked contact / swing Jacobian, column c: address in Jfoot
-	auto JCp = [&](int i, int c) { return Jf + (pick(cl, (i / 3) & 3) * 3 + i % 3) * kNU + c; };
-	auto JSp = [&](int i, int c) { return Jf + (pick(sl, (i / 3) & 3) * 3 + i % 3) * kNU + c; };
-	auto JC = [&](int i, int c) { return *JCp(i, c); };
-	auto JS = [&](int i, int c) { return *JSp(i, c); };
-	const Entry zero = {M, 0.0, 0.0};
-
+	const WbcCtx x = wbc_ctx(a.in, inst);
+	const bool all = a.write_all != 0;
 	if (lane == 0) {
-		a.n_inst[inst] = n;
+		a.n_inst[inst] = x.n;
 		int *mi = a.m_inst + (size_t)inst * 5, *pi = a.p_inst + (size_t)inst * 5;
-		mi[0] = kNB;
-		mi[1] = 0;
-		mi[2] = 3 * nc;
-		mi[3] = 6 + 3 * ns;
-		mi[4] = 3 * nc;
-		pi[0] = 0;
-		pi[1] = 2 * kNJ + 4 * nc;
-		pi[2] = pi[3] = pi[4] = 0;
-	}
-	// level 0: ConstructFloatingBaseEomTask, :351-366
-	{
-		double *A = a.A0 + (size_t)inst * kNB * kNX;
-		fill_block<kNB * kNX>(A, kNB * kNX, [&](int idx) {
-			const int r = idx / kNX, c = idx - r * kNX;
-			Entry e = zero;
-			if (c < kNU)
-				e = {M + r * kNU + c, 1.0, 0.0};
-			else if (c < n)
-				e = {JCp(c - kNU, r), -1.0, 0.0};
-			return e;
-		});
-		if (lane < kNB)
-			a.b0[(size_t)inst * kNB + lane] = -h[lane];
-	}
-	// level 1: ConstructJointTorqueTask :332-349 ++ ConstructFrictionConeTask :299-330
-	{
-		double *D = a.D1 + (size_t)inst * 40 * kNX;
-		double *f = a.f1 + (size_t)inst * 40;
-		fill_block<40 * kNX>(D, (2 * kNJ + 4 * nc) * kNX, [&](int idx) {
-			const int r = idx / kNX, c = idx - r * kNX;
-			Entry e = zero;
-			if (r < 2 * kNJ) {
-				const int rr = (r < kNJ) ? r : r - kNJ;
-				const double sg = (r < kNJ) ? 1.0 : -1.0;
-				if (c < kNU)
-					e = {M + (kNB + rr) * kNU + c, sg, 0.0};
-				else if (c < n)
-					e = {JCp(c - kNU, kNB + rr), -sg, 0.0};
-			} else if (r < 2 * kNJ + 4 * nc) {
-				const int i = (r - 2 * kNJ) / 4, t = (r - 2 * kNJ) % 4;
-				const int col = a.friction_quirk ? kNB + pick(cl, i) * 3 : kNU + 3 * i;
-				const int d = c - col;
-				if (d == 2)
-					e.add = -a.mu;
-				else if (d == 0 && t < 2)
-					e.add = (t == 0) ? 1.0 : -1.0;
-				else if (d == 1 && t >= 2)
-					e.add = (t == 2) ? 1.0 : -1.0;
-			}
-			return e;
-		});
-		if (lane < 40) {
-			double v = 0.0;
-			if (lane < kNJ)
-				v = a.tau_max - h[kNB + lane];
-			else if (lane < 2 * kNJ)
-				v = -(a.tau_min - h[kNB + lane - kNJ]);
-			f[lane] = v;
+		for (int k = 0; k < 5; ++k) {
+			mi[k] = wbc_m(x, k);
+			pi[k] = wbc_p(x, k);
 		}
 	}
-	// level 2: ConstructNoContactMotionTask, :283-297
-	{
-		double *A = a.A2 + (size_t)inst * 12 * kNX;
-		fill_block<12 * kNX>(A, 3 * nc * kNX, [&](int idx) {
-			const int r = idx / kNX, c = idx - r * kNX;
-			Entry e = zero;
-			if (r < 3 * nc && c < kNU)
-				e = {JCp(r, c), 1.0, 0.0};
-			return e;
-		});
-		if (lane < 12)
-			a.b2[(size_t)inst * 12 + lane] = (lane < 3 * nc) ? -Jdu[pick(cl, lane / 3) * 3 + lane % 3] : 0.0;
-	}
-	// level 3: base pos :217-247, base rot :249-281, swing legs :186-215
-	{
-		double *A = a.A3 + (size_t)inst * 18 * kNX;
-		fill_block<18 * kNX>(A, (6 + 3 * ns) * kNX, [&](int idx) {
-			const int r = idx / kNX, c = idx - r * kNX;
-			Entry e = zero;
-			if (c < kNU) {
-				if (r < 6) {
-					const int rb = (r < 3) ? 3 + r : r - 3;
-					if (Jb)
-						e = {Jb + rb * kNU + c, 1.0, 0.0};
-					else
-						e.add = (rb == c) ? 1.0 : 0.0;
-				} else if (r < 6 + 3 * ns) {
-					e = {JSp(r - 6, c), 1.0, 0.0};
-				}
-			}
-			return e;
-		});
-		if (lane < 18) {
-			double v = 0.0;
-			if (lane < 3) {
-				v = bc[6 + lane] + a.kv_base * (bc[3 + lane] - u[3 + lane]);
-				if (!a.drop_base_gain)
-					v += a.kp_base * (bc[lane] - q[4 + lane]);
-			} else if (lane < 6) {
-				v = a.kv_rot * (0.0 - u[lane - 3]);
-			} else if (lane < 6 + 3 * ns) {
-				int i = lane - 6;
-				double vel = 0.0;
-				for (int c = 0; c < kNU; ++c)
-					vel = fma(JS(i, c), u[c], vel);
-				int li = pick(sl, i / 3) * 3 + i % 3;
-				v = lc[24 + li] + a.kp_swing * (lc[li] - fp[li]) + a.kv_swing * (lc[12 + li] - vel);
-			}
-			a.b3[(size_t)inst * 18 + lane] = v;
-		}
-	}
-	// level 4: ConstructForceMinimizationTask, :385-400
-	{
-		double *A = a.A4 + (size_t)inst * 12 * kNX;
-		fill_block<12 * kNX>(A, 3 * nc * kNX, [&](int idx) {
-			const int r = idx / kNX, c = idx - r * kNX;
-			Entry e = zero;
-			e.add = (r < 3 * nc && c == kNU + r) ? 1.0 : 0.0;
-			return e;
-		});
-		if (lane < 12)
-			a.b4[(size_t)inst * 12 + lane] = 0.0;
-	}
+	build_level<0, 6>(x, a.prm, a.A0 + (size_t)inst * 6 * kNX, a.b0 + (size_t)inst * 6, wbc_m(x, 0), all);
+	build_level<1, 40>(x, a.prm, a.D1 + (size_t)inst * 40 * kNX, a.f1 + (size_t)inst * 40, wbc_p(x, 1), all);
+	build_level<2, 12>(x, a.prm, a.A2 + (size_t)inst * 12 * kNX, a.b2 + (size_t)inst * 12, wbc_m(x, 2), all);
+	build_level<3, 18>(x, a.prm, a.A3 + (size_t)inst * 18 * kNX, a.b3 + (size_t)inst * 18, wbc_m(x, 3), all);
+	build_level<4, 12>(x, a.prm, a.A4 + (size_t)inst * 12 * kNX, a.b4 + (size_t)inst * 12, wbc_m(x, 4), all);
 }
 
 // q_j_ddot = x[6:18] (ho_qp_controller.cpp:23); tau = [M_j, -J_c_j^T] x + c_j (:67-73)
-__global__ void wbc_finalize_kernel(hoqp_wbc_inputs in, const double *x, double *qdd, double *tau)
+__global__ void wbc_finalize_kernel(hoqp_wbc_inputs in, const double *x, double *qdd, double *tau, int *status)
 {
 	int t = blockIdx.x * blockDim.x + threadIdx.x;
 	int inst = t / kNJ, r = t - inst * kNJ;
@@ -272,6 +147,8 @@ __global__ void wbc_finalize_kernel(hoqp_wbc_inputs in, const double *x, double 
 				++i;
 			}
 		tau[(size_t)inst * kNJ + r] = acc;
+		if (status && !isfinite(acc))
+			atomicOr(status + inst, HOQP_STATUS_NONFINITE);
 	}
 }
 
@@ -332,11 +209,20 @@ __global__ void __launch_bounds__(kWave) selftest_kernel(int *fail)
 // ===========================================================================
 using namespace hoqp;
 
+namespace {
+constexpr size_t kTaskDoubles = 180 + 6 + 1200 + 40 + 360 + 12 + 540 + 18 + 360 + 12;  // per instance
+constexpr size_t kTaskInts = 11;						       // n, m[5], p[5]
+constexpr int kMaxDevices = 64;
+}  // namespace
+
 struct hoqp_handle {
 	hoqp_config cfg;
 	std::string err;
 	int max_lds = 0;
-	// WBC task workspace (grow-only)
+	// grow-only staging of the host-buffer entries: one device arena + one pinned host arena
+	char *stage_d = nullptr, *stage_h = nullptr;
+	size_t stage_cap = 0;
+	// task workspace of the unfused path (hoqp_solve_wbc_batched with HOQP_OPT_UNFUSED_WBC), grow-only
 	int ws_batch = 0;
 	double *ws_d = nullptr;
 	int *ws_i = nullptr;
@@ -359,6 +245,31 @@ static int fail(hoqp_handle *h, int code, const std::string &msg)
 			return fail(h, -3, std::string(#call) + ": " + hipGetErrorString(e_)); \
 	} while (0)
 
+// Makes the handle's device current for the duration of an entry point and restores the caller's
+// current device afterwards (a process that drives several GPUs keeps its own notion of "current").
+namespace {
+struct DeviceScope {
+	int prev = -1;
+	hipError_t err = hipSuccess;
+	explicit DeviceScope(int dev)
+	{
+		if (hipGetDevice(&prev) != hipSuccess)
+			prev = -1;
+		if (prev != dev)
+			err = hipSetDevice(dev);
+	}
+	~DeviceScope()
+	{
+		int cur = -1;
+		if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev)
+			(void)hipSetDevice(prev);
+	}
+};
+}  // namespace
+#define ENTER_DEVICE(h)                   \
+	DeviceScope dev_scope_(h->cfg.device); \
+	HIP_OK(h, dev_scope_.err)
+
 extern "C" void hoqp_default_config(hoqp_config *cfg)
 {
 	std::memset(cfg, 0, sizeof(*cfg));
@@ -376,17 +287,14 @@ extern "C" int hoqp_create(const hoqp_config *cfg, hoqp_handle **out)
 {
 	if (!cfg || !out)
 		return -1;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || cfg->device < 0 || cfg->device >= ndev || cfg->device >= kMaxDevices)
+		return -2;
+	DeviceScope scope(cfg->device);
+	if (scope.err != hipSuccess)
+		return -3;
 	hoqp_handle *h = new hoqp_handle();
 	h->cfg = *cfg;
-	int ndev = 0;
-	if (hipGetDeviceCount(&ndev) != hipSuccess || cfg->device < 0 || cfg->device >= ndev) {
-		delete h;
-		return -2;
-	}
-	if (hipSetDevice(cfg->device) != hipSuccess) {
-		delete h;
-		return -3;
-	}
 	int lds = 0;
 	if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, cfg->device) != hipSuccess)
 		lds = 65536;
@@ -399,7 +307,7 @@ extern "C" int hoqp_destroy(hoqp_handle *h)
 {
 	if (!h)
 		return -1;
-	(void)hipSetDevice(h->cfg.device);
+	DeviceScope scope(h->cfg.device);
 	for (auto &e : h->ev) {
 		(void)hipEventDestroy(e.first);
 		(void)hipEventDestroy(e.second);
@@ -408,11 +316,44 @@ extern "C" int hoqp_destroy(hoqp_handle *h)
 		(void)hipFree(h->ws_d);
 	if (h->ws_i)
 		(void)hipFree(h->ws_i);
+	if (h->stage_d)
+		(void)hipFree(h->stage_d);
+	if (h->stage_h)
+		(void)hipHostFree(h->stage_h);
 	delete h;
 	return 0;
 }
 
 extern "C" const char *hoqp_last_error_string(const hoqp_handle *h) { return h ? h->err.c_str() : "null handle"; }
+
+static void fill_common(hoqp_handle *h, SolveArgs *a)
+{
+	a->gate_prior = (h->cfg.semantics & HOQP_Q2_GATE_PRIOR_INEQ) ? 1 : 0;
+	a->slack_quirk = (h->cfg.semantics & HOQP_Q3_SLACK_ORDER) ? 1 : 0;
+	a->max_iter = h->cfg.max_iter > 0 ? h->cfg.max_iter : 200;
+	a->eps = h->cfg.eps;
+	// which levels look at stored inequality rows, and does any of them also carry equality rows?
+	a->use_bl = 0;
+	a->any_hard = 0;
+	a->last_ineq_use = -1;
+	int seen = 0, P = 0, mm = 0;
+	for (int k = 0; k < a->L; ++k) {
+		const bool looks = a->gate_prior ? (a->p[k] > 0) : (a->p[k] > 0 || seen > 0);
+		if (looks) {
+			a->last_ineq_use = k;
+			if (seen > 0)
+				a->any_hard = 1;
+			if (a->m[k] > 0)
+				a->use_bl = 1;
+		}
+		seen += a->p[k];
+		P += a->p[k];
+		mm = std::max(mm, a->m[k]);
+	}
+	a->Ptot = P;
+	a->mmax = mm;
+	a->ld = a->n | 1;
+}
 
 static int fill_args(hoqp_handle *h, const hoqp_task_batch *t, const hoqp_result_batch *out, SolveArgs *a)
 {
@@ -426,10 +367,10 @@ static int fill_args(hoqp_handle *h, const hoqp_task_batch *t, const hoqp_result
 	a->batch = t->batch;
 	a->n = t->n;
 	a->L = t->num_levels;
-	int P = 0, mm = 0;
+	int P = 0;
 	for (int k = 0; k < t->num_levels; ++k) {
-		if (t->m[k] < 0 || t->m[k] > HOQP_MAX_EQ_ROWS || t->p[k] < 0)
-			return fail(h, -1, "level row counts out of range");
+		if (t->m[k] < 0 || t->m[k] > HOQP_MAX_EQ_ROWS || t->p[k] < 0 || t->p[k] > HOQP_MAX_INEQ_ROWS)
+			return fail(h, -1, "level row counts out of range (m <= HOQP_MAX_EQ_ROWS, p <= HOQP_MAX_INEQ_ROWS)");
 		if ((t->m[k] > 0 && (!t->A[k] || !t->b[k])) || (t->p[k] > 0 && (!t->D[k] || !t->f[k])))
 			return fail(h, -1, "null task block for a level with rows");
 		a->m[k] = t->m[k];
@@ -439,7 +380,6 @@ static int fill_args(hoqp_handle *h, const hoqp_task_batch *t, const hoqp_result
 		a->D[k] = t->D[k];
 		a->f[k] = t->f[k];
 		P += t->p[k];
-		mm = std::max(mm, t->m[k]);
 	}
 	if (P > HOQP_MAX_INEQ_ROWS)
 		return fail(h, -1, "more than HOQP_MAX_INEQ_ROWS inequality rows in the hierarchy");
@@ -448,32 +388,8 @@ static int fill_args(hoqp_handle *h, const hoqp_task_batch *t, const hoqp_result
 	a->n_inst = t->n_inst;
 	a->m_inst = t->m_inst;
 	a->p_inst = t->p_inst;
-	a->gate_prior = (h->cfg.semantics & HOQP_Q2_GATE_PRIOR_INEQ) ? 1 : 0;
-	a->slack_quirk = (h->cfg.semantics & HOQP_Q3_SLACK_ORDER) ? 1 : 0;
-	a->max_iter = h->cfg.max_iter > 0 ? h->cfg.max_iter : 200;
-	a->eps = h->cfg.eps;
 	a->out = *out;
-	a->Ptot = P;
-	a->mmax = mm;
-	// which levels look at stored inequality rows, and does any of them also carry equality rows?
-	a->use_bl = 0;
-	a->any_hard = 0;
-	a->last_ineq_use = -1;
-	{
-		int seen = 0;
-		for (int k = 0; k < t->num_levels; ++k) {
-			const bool looks = a->gate_prior ? (t->p[k] > 0) : (t->p[k] > 0 || seen > 0);
-			if (looks) {
-				a->last_ineq_use = k;
-				if (seen > 0)
-					a->any_hard = 1;
-				if (t->m[k] > 0)
-					a->use_bl = 1;
-			}
-			seen += t->p[k];
-		}
-	}
-	a->ld = t->n | 1;
+	fill_common(h, a);
 	return 0;
 }
 
@@ -496,7 +412,9 @@ extern "C" size_t hoqp_lds_bytes(int n, int num_levels, const int *m, const int 
 	return (size_t)lds_offsets(a).total;
 }
 
-static int launch_solve(hoqp_handle *h, SolveArgs &a, hipStream_t s)
+// `timed`: record HIP events around the launch when the handle's timing is on (creates events: never
+// on the allocation-free path)
+static int launch_solve(hoqp_handle *h, SolveArgs &a, hipStream_t s, bool wbc, bool timed = true)
 {
 #ifdef HOQP_PROFILE
 	// profiling build: per-section cycle stamps of one launch, printed to stderr
@@ -547,16 +465,23 @@ static int launch_solve(hoqp_handle *h, SolveArgs &a, hipStream_t s)
 	size_t lds = (size_t)lds_offsets(a).total;
 	if ((int)lds > h->max_lds)
 		return fail(h, -5, "LDS workspace " + std::to_string(lds) + " B exceeds the device limit");
-	// three instantiations: no level looks at rows stored by an earlier one (the WBC hierarchy under
-	// reference semantics) / gated / ungated
-	auto kern = !a.any_hard ? hoqp_solve_kernel<true, false>
-				: (a.gate_prior ? hoqp_solve_kernel<true, true> : hoqp_solve_kernel<false, true>);
+	// instantiations: no level looks at rows stored by an earlier one (the WBC hierarchy under
+	// reference semantics) / gated / ungated; the fused WBC entry has a single inequality level, so
+	// it is either <gated, no hard rows> or <ungated, hard rows>
+	void (*kern)(const SolveArgs);
+	if (wbc)
+		kern = !a.any_hard ? hoqp_solve_kernel<true, false, true> : hoqp_solve_kernel<false, true, true>;
+	else
+		kern = !a.any_hard ? hoqp_solve_kernel<true, false, false>
+				   : (a.gate_prior ? hoqp_solve_kernel<true, true, false> : hoqp_solve_kernel<false, true, false>);
+	if (wbc && a.any_hard && a.gate_prior)
+		return fail(h, -1, "internal: gated WBC hierarchy with hard rows");
 	if (lds > 48 * 1024)
 		HIP_OK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 	if (a.batch == 0)
 		return 0;
 	hipEvent_t e0 = nullptr, e1 = nullptr;
-	if (h->timing && h->ev.size() < 100000) {
+	if (timed && h->timing && h->ev.size() < 100000) {
 		HIP_OK(h, hipEventCreate(&e0));
 		HIP_OK(h, hipEventCreate(&e1));
 		HIP_OK(h, hipEventRecord(e0, s));
@@ -575,55 +500,17 @@ extern "C" int hoqp_solve_tasks_batched(hoqp_handle *h, const hoqp_task_batch *t
 {
 	if (!h)
 		return -1;
-	HIP_OK(h, hipSetDevice(h->cfg.device));
+	ENTER_DEVICE(h);
 	SolveArgs a;
 	int rc = fill_args(h, tasks, out, &a);
 	if (rc)
 		return rc;
-	return launch_solve(h, a, (hipStream_t)stream);
+	return launch_solve(h, a, (hipStream_t)stream, false);
 }
 
-// storage extents of the WBC hierarchy (n = 30; rows at n_c = 4 / n_s = 4 maxima)
-static const int kWbcM[5] = {6, 0, 12, 18, 12};
-static const int kWbcP[5] = {0, 40, 0, 0, 0};
-
-extern "C" int hoqp_solve_wbc_batched(hoqp_handle *h, const hoqp_wbc_inputs *in, const hoqp_wbc_outputs *out,
-				      void *stream)
+static WbcPrm wbc_params(const hoqp_handle *h)
 {
-	if (!h)
-		return -1;
-	if (!in || !out)
-		return fail(h, -1, "null argument");
-	if (in->batch < 0)
-		return fail(h, -1, "negative batch");
-	if (!in->M || !in->h || !in->Jfoot || !in->Jdotu || !in->footpos || !in->q || !in->u || !in->base_cmd ||
-	    !in->leg_cmd || !in->contact)
-		return fail(h, -1, "null WBC input array");
-	if (!out->x)
-		return fail(h, -1, "hoqp_wbc_outputs.x is required");
-	HIP_OK(h, hipSetDevice(h->cfg.device));
-	hipStream_t s = (hipStream_t)stream;
-	const int B = in->batch;
-	if (B == 0)
-		return 0;
-	// per-instance doubles: A0 180 + b0 6 + D1 1200 + f1 40 + A2 360 + b2 12 + A3 540 + b3 18 + A4 360 + b4 12
-	const size_t per_d = 180 + 6 + 1200 + 40 + 360 + 12 + 540 + 18 + 360 + 12;
-	if (B > h->ws_batch) {
-		HIP_OK(h, hipStreamSynchronize(s));
-		if (h->ws_d)
-			HIP_OK(h, hipFree(h->ws_d));
-		if (h->ws_i)
-			HIP_OK(h, hipFree(h->ws_i));
-		h->ws_d = nullptr;
-		h->ws_i = nullptr;
-		h->ws_batch = 0;
-		HIP_OK(h, hipMalloc(&h->ws_d, sizeof(double) * per_d * B));
-		HIP_OK(h, hipMalloc(&h->ws_i, sizeof(int) * 11 * B));
-		h->ws_batch = B;
-	}
-	WbcArgs w;
-	std::memset(&w, 0, sizeof(w));
-	w.in = *in;
+	WbcPrm w;
 	w.friction_quirk = (h->cfg.semantics & HOQP_Q1_FRICTION_COLS) ? 1 : 0;
 	w.drop_base_gain = (h->cfg.semantics & HOQP_Q5_DROP_BASE_POS_GAIN) ? 1 : 0;
 	w.mu = h->cfg.mu;
@@ -634,7 +521,85 @@ extern "C" int hoqp_solve_wbc_batched(hoqp_handle *h, const hoqp_wbc_inputs *in,
 	w.kp_base = h->cfg.kp_base;
 	w.kv_base = h->cfg.kv_base;
 	w.kv_rot = h->cfg.kv_rot;
-	double *d = h->ws_d;
+	return w;
+}
+
+static int check_wbc_args(hoqp_handle *h, const hoqp_wbc_inputs *in, const hoqp_wbc_outputs *out)
+{
+	if (!in || !out)
+		return fail(h, -1, "null argument");
+	if (in->batch < 0)
+		return fail(h, -1, "negative batch");
+	if (!in->M || !in->h || !in->Jfoot || !in->Jdotu || !in->footpos || !in->q || !in->u || !in->base_cmd ||
+	    !in->leg_cmd || !in->contact)
+		return fail(h, -1, "null WBC input array");
+	if (!out->x)
+		return fail(h, -1, "hoqp_wbc_outputs.x is required");
+	return 0;
+}
+
+static hoqp_result_batch wbc_results(const hoqp_wbc_outputs *out)
+{
+	hoqp_result_batch r;
+	std::memset(&r, 0, sizeof(r));
+	r.x = out->x;
+	r.x_levels = out->x_levels;
+	r.v = out->v;
+	r.level_res = out->level_res;
+	r.nz_levels = out->nz_levels;
+	r.iters = out->iters;
+	r.status = out->status;
+	r.flags = out->flags;
+	r.eq_res_max = out->eq_res_max;
+	r.ineq_viol_max = out->ineq_viol_max;
+	r.active_mask = out->active_mask;
+	return r;
+}
+
+// Fused entry: ONE kernel.  The task blocks are generated inside the solve kernel (wbc_tasks.hpp),
+// tau / q_j_ddot / validity flags come out of its tail; nothing is staged through HBM and the
+// handle holds no workspace for it.
+extern "C" int hoqp_solve_wbc_batched(hoqp_handle *h, const hoqp_wbc_inputs *in, const hoqp_wbc_outputs *out,
+				      void *stream)
+{
+	if (!h)
+		return -1;
+	int rc = check_wbc_args(h, in, out);
+	if (rc)
+		return rc;
+	if (in->batch == 0)
+		return 0;
+	ENTER_DEVICE(h);
+	SolveArgs a;
+	std::memset(&a, 0, sizeof(a));
+	a.batch = in->batch;
+	a.n = kNX;
+	a.L = 5;
+	for (int k = 0; k < 5; ++k) {
+		a.m[k] = kWbcMmax[k];
+		a.p[k] = kWbcPmax[k];
+	}
+	a.out = wbc_results(out);
+	a.win = *in;
+	a.wprm = wbc_params(h);
+	a.qdd = out->qdd;
+	a.tau = out->tau;
+	fill_common(h, &a);
+	return launch_solve(h, a, (hipStream_t)stream, true);
+}
+
+// Unfused path on caller-chosen task storage: wbc_build_kernel -> generic solve -> wbc_finalize_kernel.
+// ws_d: kTaskDoubles * B doubles, ws_i: kTaskInts * B ints (device).
+static int solve_wbc_unfused(hoqp_handle *h, const hoqp_wbc_inputs *in, const hoqp_wbc_outputs *out, hipStream_t s,
+			     double *ws_d, int *ws_i, bool timed)
+{
+	const int B = in->batch;
+	WbcArgs w;
+	std::memset(&w, 0, sizeof(w));
+	w.in = *in;
+	w.prm = wbc_params(h);
+	w.write_all = 0;
+	double *d = ws_d;
 	w.A0 = d;
 	d += (size_t)180 * B;
 	w.b0 = d;
@@ -654,9 +619,9 @@ extern "C" int hoqp_solve_wbc_batched(hoqp_handle *h, const hoqp_wbc_inputs *in,
 	w.A4 = d;
 	d += (size_t)360 * B;
 	w.b4 = d;
-	w.n_inst = h->ws_i;
-	w.m_inst = h->ws_i + B;
-	w.p_inst = h->ws_i + (size_t)6 * B;
+	w.n_inst = ws_i;
+	w.m_inst = ws_i + B;
+	w.p_inst = ws_i + (size_t)6 * B;
 	hipLaunchKernelGGL(wbc_build_kernel, dim3(B), dim3(kBuildThreads), 0, s, w);
 	HIP_OK(h, hipGetLastError());
 
@@ -666,8 +631,8 @@ extern "C" int hoqp_solve_wbc_batched(hoqp_handle *h, const hoqp_wbc_inputs *in,
 	t.n = kNX;
 	t.num_levels = 5;
 	for (int k = 0; k < 5; ++k) {
-		t.m[k] = kWbcM[k];
-		t.p[k] = kWbcP[k];
+		t.m[k] = kWbcMmax[k];
+		t.p[k] = kWbcPmax[k];
 	}
 	t.A[0] = w.A0;
 	t.b[0] = w.b0;
@@ -682,32 +647,99 @@ extern "C" int hoqp_solve_wbc_batched(hoqp_handle *h, const hoqp_wbc_inputs *in,
 	t.n_inst = w.n_inst;
 	t.m_inst = w.m_inst;
 	t.p_inst = w.p_inst;
-	hoqp_result_batch r;
-	std::memset(&r, 0, sizeof(r));
-	r.x = out->x;
-	r.x_levels = out->x_levels;
-	r.v = out->v;
-	r.level_res = out->level_res;
-	r.nz_levels = out->nz_levels;
-	r.iters = out->iters;
-	r.status = out->status;
-	r.flags = out->flags;
-	r.eq_res_max = out->eq_res_max;
-	r.ineq_viol_max = out->ineq_viol_max;
-	r.active_mask = out->active_mask;
+	const hoqp_result_batch r = wbc_results(out);
 	SolveArgs a;
 	int rc = fill_args(h, &t, &r, &a);
 	if (rc)
 		return rc;
-	rc = launch_solve(h, a, s);
+	rc = launch_solve(h, a, s, false, timed);
 	if (rc)
 		return rc;
 	if (out->qdd || out->tau) {
 		int threads = B * kNJ;
 		hipLaunchKernelGGL(wbc_finalize_kernel, dim3((threads + 255) / 256), dim3(256), 0, s, *in, out->x, out->qdd,
-				   out->tau);
+				   out->tau, out->status);
 		HIP_OK(h, hipGetLastError());
 	}
+	return 0;
+}
+
+// Same results as hoqp_solve_wbc_batched through the three-kernel path (task blocks materialised in
+// a handle-owned, grow-only workspace).  Kept as the cross-check of the fused kernel.
+extern "C" int hoqp_solve_wbc_unfused(hoqp_handle *h, const hoqp_wbc_inputs *in, const hoqp_wbc_outputs *out,
+				      void *stream)
+{
+	if (!h)
+		return -1;
+	int rc = check_wbc_args(h, in, out);
+	if (rc)
+		return rc;
+	const int B = in->batch;
+	if (B == 0)
+		return 0;
+	ENTER_DEVICE(h);
+	hipStream_t s = (hipStream_t)stream;
+	if (B > h->ws_batch) {
+		HIP_OK(h, hipStreamSynchronize(s));
+		if (h->ws_d)
+			HIP_OK(h, hipFree(h->ws_d));
+		if (h->ws_i)
+			HIP_OK(h, hipFree(h->ws_i));
+		h->ws_d = nullptr;
+		h->ws_i = nullptr;
+		h->ws_batch = 0;
+		HIP_OK(h, hipMalloc(&h->ws_d, sizeof(double) * kTaskDoubles * B));
+		HIP_OK(h, hipMalloc(&h->ws_i, sizeof(int) * kTaskInts * B));
+		h->ws_batch = B;
+	}
+	return solve_wbc_unfused(h, in, out, s, h->ws_d, h->ws_i, true);
+}
+
+// HoQpController::ConstructTasks (ho_qp_controller.cpp:147-184) as a batched dump: the five task
+// blocks of every instance, rows beyond an instance's own count zeroed.
+extern "C" int hoqp_wbc_build_tasks_batched(hoqp_handle *h, const hoqp_wbc_inputs *in, const hoqp_task_batch *t,
+					    void *stream)
+{
+	if (!h)
+		return -1;
+	if (!in || !t)
+		return fail(h, -1, "null argument");
+	if (in->batch < 0 || t->batch != in->batch)
+		return fail(h, -1, "batch mismatch");
+	if (!in->M || !in->h || !in->Jfoot || !in->Jdotu || !in->footpos || !in->q || !in->u || !in->base_cmd ||
+	    !in->leg_cmd || !in->contact)
+		return fail(h, -1, "null WBC input array");
+	if (t->n != kNX || t->num_levels != 5)
+		return fail(h, -1, "hoqp_wbc_build_tasks_batched: n must be 30 and num_levels 5");
+	for (int k = 0; k < 5; ++k)
+		if (t->m[k] != kWbcMmax[k] || t->p[k] != kWbcPmax[k])
+			return fail(h, -1, "hoqp_wbc_build_tasks_batched: storage extents must be m = {6,0,12,18,12}, p = {0,40,0,0,0}");
+	if (!t->A[0] || !t->b[0] || !t->D[1] || !t->f[1] || !t->A[2] || !t->b[2] || !t->A[3] || !t->b[3] || !t->A[4] ||
+	    !t->b[4] || !t->n_inst || !t->m_inst || !t->p_inst)
+		return fail(h, -1, "hoqp_wbc_build_tasks_batched: null task block");
+	if (in->batch == 0)
+		return 0;
+	ENTER_DEVICE(h);
+	WbcArgs w;
+	std::memset(&w, 0, sizeof(w));
+	w.in = *in;
+	w.prm = wbc_params(h);
+	w.write_all = 1;
+	w.A0 = (double *)t->A[0];
+	w.b0 = (double *)t->b[0];
+	w.D1 = (double *)t->D[1];
+	w.f1 = (double *)t->f[1];
+	w.A2 = (double *)t->A[2];
+	w.b2 = (double *)t->b[2];
+	w.A3 = (double *)t->A[3];
+	w.b3 = (double *)t->b[3];
+	w.A4 = (double *)t->A[4];
+	w.b4 = (double *)t->b[4];
+	w.n_inst = (int *)t->n_inst;
+	w.m_inst = (int *)t->m_inst;
+	w.p_inst = (int *)t->p_inst;
+	hipLaunchKernelGGL(wbc_build_kernel, dim3(in->batch), dim3(kBuildThreads), 0, (hipStream_t)stream, w);
+	HIP_OK(h, hipGetLastError());
 	return 0;
 }
 
@@ -741,7 +773,7 @@ extern "C" int hoqp_wbc_dynamics_batched(hoqp_handle *h, const hoqp_quadruped_mo
 		md = *model;
 	else
 		hoqp_default_quadruped_model(&md);
-	HIP_OK(h, hipSetDevice(h->cfg.device));
+	ENTER_DEVICE(h);
 	hipLaunchKernelGGL(wbc_dynamics_kernel, dim3(batch), dim3(kWave), 0, (hipStream_t)stream, md, batch, include_gravity,
 			   q, u, M, hvec, Jfoot, Jdotu, footpos, Jb);
 	HIP_OK(h, hipGetLastError());
@@ -762,7 +794,7 @@ extern "C" int hoqp_wbc_poststep_batched(hoqp_handle *h, int batch, double dt, d
 		return fail(h, -1, "hoqp_wbc_poststep_batched: tau_cmd needs tau_ff, q_j and qd_j");
 	if (batch == 0)
 		return 0;
-	HIP_OK(h, hipSetDevice(h->cfg.device));
+	ENTER_DEVICE(h);
 	const long long total = (long long)batch * kNJ;
 	if (total > 0x7fffffffLL)
 		return fail(h, -1, "batch too large");
@@ -808,7 +840,7 @@ extern "C" int hoqp_gait_sample_batched(hoqp_handle *h, const hoqp_gait *g, int 
 		return fail(h, -1, "hoqp_gait_sample_batched: null array");
 	if (batch == 0)
 		return 0;
-	HIP_OK(h, hipSetDevice(h->cfg.device));
+	ENTER_DEVICE(h);
 	hipLaunchKernelGGL(gait_sample_kernel, dim3((4u * batch + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, *g, batch,
 			   time, vel_cmd, stance0, leg_cmd, contact);
 	HIP_OK(h, hipGetLastError());
@@ -829,7 +861,7 @@ extern "C" int hoqp_standup_sample_batched(hoqp_handle *h, int batch, const doub
 		return fail(h, -1, "hoqp_standup_sample_batched: null array");
 	if (batch == 0)
 		return 0;
-	HIP_OK(h, hipSetDevice(h->cfg.device));
+	ENTER_DEVICE(h);
 	hipLaunchKernelGGL(standup_sample_kernel, dim3((batch + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, batch,
 			   seconds_to_standup, target_height, time, curr_pose, base_cmd, contact);
 	HIP_OK(h, hipGetLastError());
@@ -850,7 +882,7 @@ extern "C" int hoqp_base_walk_sample_batched(hoqp_handle *h, int batch, const do
 		return fail(h, -1, "hoqp_base_walk_sample_batched: null array");
 	if (batch == 0)
 		return 0;
-	HIP_OK(h, hipSetDevice(h->cfg.device));
+	ENTER_DEVICE(h);
 	hipLaunchKernelGGL(base_walk_sample_kernel, dim3((batch + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, batch,
 			   n_segments, fix_layout, walking_height, time, curr_pos, final_pos, base_cmd);
 	HIP_OK(h, hipGetLastError());
@@ -858,53 +890,51 @@ extern "C" int hoqp_base_walk_sample_batched(hoqp_handle *h, int batch, const do
 }
 
 // ---------------------------------------------------------------------------
-// host-buffer convenience entry points (single-instance drop-in use: the reference calls
-// CalcJointCmd once per 2.5 ms cycle with host Eigen data, whole_body_controller.cpp:97-107)
+// host-buffer entry points (single-instance drop-in use: the reference calls CalcJointCmd once per
+// 2.5 ms cycle with host Eigen data, whole_body_controller.cpp:97-107).  Inputs are packed into the
+// handle's pinned host arena, go to the device arena in ONE copy, the kernels run, the outputs come
+// back in ONE copy.  Both arenas are grow-only: after the first call of a given size there is no
+// allocation on this path.
 // ---------------------------------------------------------------------------
 namespace {
-struct DevBuf {
-	std::vector<void *> ptrs;
-	~DevBuf()
+struct Stage {
+	size_t size = 0;
+	// reserve `bytes` (8-byte aligned) and return the offset
+	size_t take(size_t bytes)
 	{
-		for (void *p : ptrs)
-			(void)hipFree(p);
-	}
-	template <typename T>
-	hipError_t up(const T *host, size_t count, const T **dev)
-	{
-		*dev = nullptr;
-		if (!host || count == 0)
-			return hipSuccess;
-		void *d = nullptr;
-		hipError_t e = hipMalloc(&d, sizeof(T) * count);
-		if (e != hipSuccess)
-			return e;
-		ptrs.push_back(d);
-		*dev = (const T *)d;
-		return hipMemcpy(d, host, sizeof(T) * count, hipMemcpyHostToDevice);
-	}
-	template <typename T>
-	hipError_t out(T *host, size_t count, T **dev)
-	{
-		*dev = nullptr;
-		if (!host || count == 0)
-			return hipSuccess;
-		void *d = nullptr;
-		hipError_t e = hipMalloc(&d, sizeof(T) * count);
-		if (e != hipSuccess)
-			return e;
-		ptrs.push_back(d);
-		*dev = (T *)d;
-		return hipMemset(d, 0, sizeof(T) * count);
+		const size_t o = size;
+		size += (bytes + 7) & ~(size_t)7;
+		return o;
 	}
 };
-template <typename T>
-hipError_t down(T *host, const T *dev, size_t count)
+}  // namespace
+
+static int stage_reserve(hoqp_handle *h, size_t bytes)
 {
-	if (!host || !dev || count == 0)
-		return hipSuccess;
-	return hipMemcpy(host, dev, sizeof(T) * count, hipMemcpyDeviceToHost);
+	if (bytes <= h->stage_cap)
+		return 0;
+	size_t cap = std::max<size_t>(bytes, 1 << 16);
+	cap = (cap + 4095) & ~(size_t)4095;
+	HIP_OK(h, hipDeviceSynchronize());
+	if (h->stage_d)
+		HIP_OK(h, hipFree(h->stage_d));
+	if (h->stage_h)
+		HIP_OK(h, hipHostFree(h->stage_h));
+	h->stage_d = h->stage_h = nullptr;
+	h->stage_cap = 0;
+	HIP_OK(h, hipMalloc((void **)&h->stage_d, cap));
+	HIP_OK(h, hipHostMalloc((void **)&h->stage_h, cap, hipHostMallocDefault));
+	h->stage_cap = cap;
+	return 0;
 }
+
+namespace {
+// one array of a host-buffer call: host pointer, byte count, offset in the arenas
+struct Slot {
+	const void *src;  // input: copied in
+	void *dst;	  // output: copied out
+	size_t bytes, off;
+};
 }  // namespace
 
 extern "C" int hoqp_solve_tasks_host(hoqp_handle *h, const hoqp_task_batch *t, const hoqp_result_batch *o)
@@ -915,53 +945,89 @@ extern "C" int hoqp_solve_tasks_host(hoqp_handle *h, const hoqp_task_batch *t, c
 		return fail(h, -1, "null argument");
 	if (t->batch < 0 || t->n < 1 || t->n > HOQP_MAX_VARS || t->num_levels < 1 || t->num_levels > HOQP_MAX_LEVELS)
 		return fail(h, -1, "bad extents");
-	HIP_OK(h, hipSetDevice(h->cfg.device));
-	DevBuf buf;
-	hoqp_task_batch dt = *t;
 	const size_t B = t->batch, n = t->n, L = t->num_levels;
 	size_t P = 0;
 	for (size_t k = 0; k < L; ++k) {
-		if (t->m[k] < 0 || t->p[k] < 0)
-			return fail(h, -1, "negative row count");
-		HIP_OK(h, buf.up(t->A[k], B * t->m[k] * n, &dt.A[k]));
-		HIP_OK(h, buf.up(t->b[k], B * t->m[k], &dt.b[k]));
-		HIP_OK(h, buf.up(t->D[k], B * t->p[k] * n, &dt.D[k]));
-		HIP_OK(h, buf.up(t->f[k], B * t->p[k], &dt.f[k]));
+		if (t->m[k] < 0 || t->m[k] > HOQP_MAX_EQ_ROWS || t->p[k] < 0 || t->p[k] > HOQP_MAX_INEQ_ROWS)
+			return fail(h, -1, "level row counts out of range (m <= HOQP_MAX_EQ_ROWS, p <= HOQP_MAX_INEQ_ROWS)");
+		if ((t->m[k] > 0 && (!t->A[k] || !t->b[k])) || (t->p[k] > 0 && (!t->D[k] || !t->f[k])))
+			return fail(h, -1, "null task block for a level with rows");
 		P += t->p[k];
 	}
-	HIP_OK(h, buf.up(t->n_inst, B, &dt.n_inst));
-	HIP_OK(h, buf.up(t->m_inst, B * L, &dt.m_inst));
-	HIP_OK(h, buf.up(t->p_inst, B * L, &dt.p_inst));
-	hoqp_result_batch d;
-	std::memset(&d, 0, sizeof(d));
-	HIP_OK(h, buf.out(o->x, B * n, &d.x));
-	HIP_OK(h, buf.out(o->x_levels, B * L * n, &d.x_levels));
-	HIP_OK(h, buf.out(o->v, B * P, &d.v));
-	HIP_OK(h, buf.out(o->level_res, B * L, &d.level_res));
-	HIP_OK(h, buf.out(o->Z_levels, B * L * n * n, &d.Z_levels));
-	HIP_OK(h, buf.out(o->nz_levels, B * L, &d.nz_levels));
-	HIP_OK(h, buf.out(o->iters, B * L, &d.iters));
-	HIP_OK(h, buf.out(o->status, B, &d.status));
-	HIP_OK(h, buf.out(o->flags, B * L, &d.flags));
-	HIP_OK(h, buf.out(o->eq_res_max, B * L, &d.eq_res_max));
-	HIP_OK(h, buf.out(o->ineq_viol_max, B * L, &d.ineq_viol_max));
-	HIP_OK(h, buf.out(o->active_mask, B, &d.active_mask));
-	int rc = hoqp_solve_tasks_batched(h, &dt, &d, nullptr);
+	if (P > HOQP_MAX_INEQ_ROWS)
+		return fail(h, -1, "more than HOQP_MAX_INEQ_ROWS inequality rows in the hierarchy");
+	if (B == 0)
+		return 0;
+	ENTER_DEVICE(h);
+	Stage st;
+	std::vector<Slot> ins, outs;
+	auto in = [&](const void *p, size_t bytes) -> size_t {
+		if (!p || !bytes)
+			return (size_t)-1;
+		ins.push_back({p, nullptr, bytes, st.take(bytes)});
+		return ins.back().off;
+	};
+	size_t oA[HOQP_MAX_LEVELS], ob[HOQP_MAX_LEVELS], oD[HOQP_MAX_LEVELS], of[HOQP_MAX_LEVELS];
+	for (size_t k = 0; k < L; ++k) {
+		oA[k] = in(t->A[k], 8 * B * t->m[k] * n);
+		ob[k] = in(t->b[k], 8 * B * t->m[k]);
+		oD[k] = in(t->D[k], 8 * B * t->p[k] * n);
+		of[k] = in(t->f[k], 8 * B * t->p[k]);
+	}
+	const size_t on = in(t->n_inst, 4 * B), om = in(t->m_inst, 4 * B * L), op = in(t->p_inst, 4 * B * L);
+	const size_t in_bytes = st.size;
+	auto out = [&](void *p, size_t bytes) -> size_t {
+		if (!p || !bytes)
+			return (size_t)-1;
+		outs.push_back({nullptr, p, bytes, st.take(bytes)});
+		return outs.back().off;
+	};
+	const size_t ox = out(o->x, 8 * B * n), oxl = out(o->x_levels, 8 * B * L * n), ov = out(o->v, 8 * B * P);
+	const size_t olr = out(o->level_res, 8 * B * L), oZ = out(o->Z_levels, 8 * B * L * n * n);
+	const size_t onz = out(o->nz_levels, 4 * B * L), oit = out(o->iters, 4 * B * L), ost = out(o->status, 4 * B);
+	const size_t ofl = out(o->flags, 4 * B * L), oer = out(o->eq_res_max, 8 * B * L);
+	const size_t oiv = out(o->ineq_viol_max, 8 * B * L), oam = out(o->active_mask, 8 * B);
+	int rc = stage_reserve(h, st.size);
 	if (rc)
 		return rc;
-	HIP_OK(h, hipStreamSynchronize(nullptr));
-	HIP_OK(h, down(o->x, d.x, B * n));
-	HIP_OK(h, down(o->x_levels, d.x_levels, B * L * n));
-	HIP_OK(h, down(o->v, d.v, B * P));
-	HIP_OK(h, down(o->level_res, d.level_res, B * L));
-	HIP_OK(h, down(o->Z_levels, d.Z_levels, B * L * n * n));
-	HIP_OK(h, down(o->nz_levels, d.nz_levels, B * L));
-	HIP_OK(h, down(o->iters, d.iters, B * L));
-	HIP_OK(h, down(o->status, d.status, B));
-	HIP_OK(h, down(o->flags, d.flags, B * L));
-	HIP_OK(h, down(o->eq_res_max, d.eq_res_max, B * L));
-	HIP_OK(h, down(o->ineq_viol_max, d.ineq_viol_max, B * L));
-	HIP_OK(h, down(o->active_mask, d.active_mask, B));
+	for (const Slot &s : ins)
+		std::memcpy(h->stage_h + s.off, s.src, s.bytes);
+	hipStream_t stream = nullptr;
+	HIP_OK(h, hipMemcpyAsync(h->stage_d, h->stage_h, in_bytes, hipMemcpyHostToDevice, stream));
+	auto dp = [&](size_t off) -> void * { return off == (size_t)-1 ? nullptr : (void *)(h->stage_d + off); };
+	hoqp_task_batch dt = *t;
+	for (size_t k = 0; k < L; ++k) {
+		dt.A[k] = (const double *)dp(oA[k]);
+		dt.b[k] = (const double *)dp(ob[k]);
+		dt.D[k] = (const double *)dp(oD[k]);
+		dt.f[k] = (const double *)dp(of[k]);
+	}
+	dt.n_inst = (const int *)dp(on);
+	dt.m_inst = (const int *)dp(om);
+	dt.p_inst = (const int *)dp(op);
+	hoqp_result_batch d;
+	std::memset(&d, 0, sizeof(d));
+	d.x = (double *)dp(ox);
+	d.x_levels = (double *)dp(oxl);
+	d.v = (double *)dp(ov);
+	d.level_res = (double *)dp(olr);
+	d.Z_levels = (double *)dp(oZ);
+	d.nz_levels = (int *)dp(onz);
+	d.iters = (int *)dp(oit);
+	d.status = (int *)dp(ost);
+	d.flags = (int *)dp(ofl);
+	d.eq_res_max = (double *)dp(oer);
+	d.ineq_viol_max = (double *)dp(oiv);
+	d.active_mask = (unsigned long long *)dp(oam);
+	rc = hoqp_solve_tasks_batched(h, &dt, &d, stream);
+	if (rc)
+		return rc;
+	if (st.size > in_bytes)
+		HIP_OK(h, hipMemcpyAsync(h->stage_h + in_bytes, h->stage_d + in_bytes, st.size - in_bytes, hipMemcpyDeviceToHost,
+					 stream));
+	HIP_OK(h, hipStreamSynchronize(stream));
+	for (const Slot &s : outs)
+		std::memcpy(s.dst, h->stage_h + s.off, s.bytes);
 	return 0;
 }
 
@@ -969,59 +1035,81 @@ extern "C" int hoqp_solve_wbc_host(hoqp_handle *h, const hoqp_wbc_inputs *in, co
 {
 	if (!h)
 		return -1;
-	if (!in || !o)
-		return fail(h, -1, "null argument");
-	if (in->batch < 0)
-		return fail(h, -1, "negative batch");
-	HIP_OK(h, hipSetDevice(h->cfg.device));
-	DevBuf buf;
-	const size_t B = in->batch;
-	hoqp_wbc_inputs di = *in;
-	HIP_OK(h, buf.up(in->M, B * 324, &di.M));
-	HIP_OK(h, buf.up(in->h, B * 18, &di.h));
-	HIP_OK(h, buf.up(in->Jfoot, B * 216, &di.Jfoot));
-	HIP_OK(h, buf.up(in->Jdotu, B * 12, &di.Jdotu));
-	HIP_OK(h, buf.up(in->footpos, B * 12, &di.footpos));
-	HIP_OK(h, buf.up(in->Jb, B * 108, &di.Jb));
-	HIP_OK(h, buf.up(in->q, B * 19, &di.q));
-	HIP_OK(h, buf.up(in->u, B * 18, &di.u));
-	HIP_OK(h, buf.up(in->base_cmd, B * 9, &di.base_cmd));
-	HIP_OK(h, buf.up(in->leg_cmd, B * 36, &di.leg_cmd));
-	HIP_OK(h, buf.up(in->contact, B * 4, &di.contact));
-	hoqp_wbc_outputs d;
-	std::memset(&d, 0, sizeof(d));
-	double *xtmp = nullptr;
-	HIP_OK(h, buf.out(o->x ? o->x : (double *)1, B * 30, &xtmp));
-	d.x = xtmp;
-	HIP_OK(h, buf.out(o->qdd, B * 12, &d.qdd));
-	HIP_OK(h, buf.out(o->tau, B * 12, &d.tau));
-	HIP_OK(h, buf.out(o->v, B * 40, &d.v));
-	HIP_OK(h, buf.out(o->flags, B * 5, &d.flags));
-	HIP_OK(h, buf.out(o->eq_res_max, B * 5, &d.eq_res_max));
-	HIP_OK(h, buf.out(o->ineq_viol_max, B * 5, &d.ineq_viol_max));
-	HIP_OK(h, buf.out(o->level_res, B * 5, &d.level_res));
-	HIP_OK(h, buf.out(o->active_mask, B, &d.active_mask));
-	HIP_OK(h, buf.out(o->status, B, &d.status));
-	HIP_OK(h, buf.out(o->iters, B * 5, &d.iters));
-	HIP_OK(h, buf.out(o->nz_levels, B * 5, &d.nz_levels));
-	HIP_OK(h, buf.out(o->x_levels, B * 150, &d.x_levels));
-	int rc = hoqp_solve_wbc_batched(h, &di, &d, nullptr);
+	int rc = check_wbc_args(h, in, o);
 	if (rc)
 		return rc;
-	HIP_OK(h, hipStreamSynchronize(nullptr));
-	HIP_OK(h, down(o->x, (const double *)d.x, B * 30));
-	HIP_OK(h, down(o->qdd, (const double *)d.qdd, B * 12));
-	HIP_OK(h, down(o->tau, (const double *)d.tau, B * 12));
-	HIP_OK(h, down(o->v, (const double *)d.v, B * 40));
-	HIP_OK(h, down(o->flags, (const int *)d.flags, B * 5));
-	HIP_OK(h, down(o->eq_res_max, (const double *)d.eq_res_max, B * 5));
-	HIP_OK(h, down(o->ineq_viol_max, (const double *)d.ineq_viol_max, B * 5));
-	HIP_OK(h, down(o->level_res, (const double *)d.level_res, B * 5));
-	HIP_OK(h, down(o->active_mask, (const unsigned long long *)d.active_mask, B));
-	HIP_OK(h, down(o->status, (const int *)d.status, B));
-	HIP_OK(h, down(o->iters, (const int *)d.iters, B * 5));
-	HIP_OK(h, down(o->nz_levels, (const int *)d.nz_levels, B * 5));
-	HIP_OK(h, down(o->x_levels, (const double *)d.x_levels, B * 150));
+	const size_t B = in->batch;
+	if (B == 0)
+		return 0;
+	ENTER_DEVICE(h);
+	Stage st;
+	Slot ins[11], outs[13];
+	int ni = 0, no = 0;
+	auto inp = [&](const void *p, size_t bytes) -> size_t {
+		if (!p)
+			return (size_t)-1;
+		ins[ni] = {p, nullptr, bytes, st.take(bytes)};
+		return ins[ni++].off;
+	};
+	const size_t iM = inp(in->M, 8 * B * 324), ih = inp(in->h, 8 * B * 18), iJf = inp(in->Jfoot, 8 * B * 216);
+	const size_t iJd = inp(in->Jdotu, 8 * B * 12), ifp = inp(in->footpos, 8 * B * 12), iJb = inp(in->Jb, 8 * B * 108);
+	const size_t iq = inp(in->q, 8 * B * 19), iu = inp(in->u, 8 * B * 18), ibc = inp(in->base_cmd, 8 * B * 9);
+	const size_t ilc = inp(in->leg_cmd, 8 * B * 36), ict = inp(in->contact, 4 * B * 4);
+	const size_t in_bytes = st.size;
+	auto outp = [&](void *p, size_t bytes) -> size_t {
+		if (!p)
+			return (size_t)-1;
+		outs[no] = {nullptr, p, bytes, st.take(bytes)};
+		return outs[no++].off;
+	};
+	const size_t ox = outp(o->x, 8 * B * 30), oqdd = outp(o->qdd, 8 * B * 12), otau = outp(o->tau, 8 * B * 12);
+	const size_t ov = outp(o->v, 8 * B * 40), ofl = outp(o->flags, 4 * B * 5), oer = outp(o->eq_res_max, 8 * B * 5);
+	const size_t oiv = outp(o->ineq_viol_max, 8 * B * 5), olr = outp(o->level_res, 8 * B * 5);
+	const size_t oam = outp(o->active_mask, 8 * B), ost = outp(o->status, 4 * B), oit = outp(o->iters, 4 * B * 5);
+	const size_t onz = outp(o->nz_levels, 4 * B * 5), oxl = outp(o->x_levels, 8 * B * 150);
+	rc = stage_reserve(h, st.size);
+	if (rc)
+		return rc;
+	for (int i = 0; i < ni; ++i)
+		std::memcpy(h->stage_h + ins[i].off, ins[i].src, ins[i].bytes);
+	hipStream_t stream = nullptr;
+	HIP_OK(h, hipMemcpyAsync(h->stage_d, h->stage_h, in_bytes, hipMemcpyHostToDevice, stream));
+	auto dp = [&](size_t off) -> void * { return off == (size_t)-1 ? nullptr : (void *)(h->stage_d + off); };
+	hoqp_wbc_inputs di;
+	di.batch = in->batch;
+	di.M = (const double *)dp(iM);
+	di.h = (const double *)dp(ih);
+	di.Jfoot = (const double *)dp(iJf);
+	di.Jdotu = (const double *)dp(iJd);
+	di.footpos = (const double *)dp(ifp);
+	di.Jb = (const double *)dp(iJb);
+	di.q = (const double *)dp(iq);
+	di.u = (const double *)dp(iu);
+	di.base_cmd = (const double *)dp(ibc);
+	di.leg_cmd = (const double *)dp(ilc);
+	di.contact = (const int *)dp(ict);
+	hoqp_wbc_outputs d;
+	std::memset(&d, 0, sizeof(d));
+	d.x = (double *)dp(ox);
+	d.qdd = (double *)dp(oqdd);
+	d.tau = (double *)dp(otau);
+	d.v = (double *)dp(ov);
+	d.flags = (int *)dp(ofl);
+	d.eq_res_max = (double *)dp(oer);
+	d.ineq_viol_max = (double *)dp(oiv);
+	d.level_res = (double *)dp(olr);
+	d.active_mask = (unsigned long long *)dp(oam);
+	d.status = (int *)dp(ost);
+	d.iters = (int *)dp(oit);
+	d.nz_levels = (int *)dp(onz);
+	d.x_levels = (double *)dp(oxl);
+	rc = hoqp_solve_wbc_batched(h, &di, &d, stream);
+	if (rc)
+		return rc;
+	HIP_OK(h, hipMemcpyAsync(h->stage_h + in_bytes, h->stage_d + in_bytes, st.size - in_bytes, hipMemcpyDeviceToHost, stream));
+	HIP_OK(h, hipStreamSynchronize(stream));
+	for (int i = 0; i < no; ++i)
+		std::memcpy(outs[i].dst, h->stage_h + outs[i].off, outs[i].bytes);
 	return 0;
 }
 
@@ -1035,29 +1123,38 @@ extern "C" int hoqp_wbc_dynamics_host(hoqp_handle *h, const hoqp_quadruped_model
 		return fail(h, -1, "negative batch");
 	if (!q || !u || !M || !hvec || !Jfoot || !Jdotu || !footpos)
 		return fail(h, -1, "hoqp_wbc_dynamics_host: null array");
-	HIP_OK(h, hipSetDevice(h->cfg.device));
-	DevBuf buf;
+	if (batch == 0)
+		return 0;
+	ENTER_DEVICE(h);
 	const size_t B = batch;
-	const double *dq = nullptr, *du = nullptr;
-	HIP_OK(h, buf.up(q, B * 19, &dq));
-	HIP_OK(h, buf.up(u, B * 18, &du));
-	double *dM = nullptr, *dh = nullptr, *dJf = nullptr, *dJdu = nullptr, *dfp = nullptr, *dJb = nullptr;
-	HIP_OK(h, buf.out(M, B * 324, &dM));
-	HIP_OK(h, buf.out(hvec, B * 18, &dh));
-	HIP_OK(h, buf.out(Jfoot, B * 216, &dJf));
-	HIP_OK(h, buf.out(Jdotu, B * 12, &dJdu));
-	HIP_OK(h, buf.out(footpos, B * 12, &dfp));
-	HIP_OK(h, buf.out(Jb, B * 108, &dJb));
-	int rc = hoqp_wbc_dynamics_batched(h, model, batch, dq, du, include_gravity, dM, dh, dJf, dJdu, dfp, dJb, nullptr);
+	Stage st;
+	const size_t iq = st.take(8 * B * 19), iu = st.take(8 * B * 18);
+	const size_t in_bytes = st.size;
+	const size_t oM = st.take(8 * B * 324), oh = st.take(8 * B * 18), oJf = st.take(8 * B * 216);
+	const size_t oJd = st.take(8 * B * 12), ofp = st.take(8 * B * 12), oJb = st.take(8 * B * 108);
+	int rc = stage_reserve(h, st.size);
 	if (rc)
 		return rc;
-	HIP_OK(h, hipStreamSynchronize(nullptr));
-	HIP_OK(h, down(M, (const double *)dM, B * 324));
-	HIP_OK(h, down(hvec, (const double *)dh, B * 18));
-	HIP_OK(h, down(Jfoot, (const double *)dJf, B * 216));
-	HIP_OK(h, down(Jdotu, (const double *)dJdu, B * 12));
-	HIP_OK(h, down(footpos, (const double *)dfp, B * 12));
-	HIP_OK(h, down(Jb, (const double *)dJb, B * 108));
+	std::memcpy(h->stage_h + iq, q, 8 * B * 19);
+	std::memcpy(h->stage_h + iu, u, 8 * B * 18);
+	hipStream_t stream = nullptr;
+	HIP_OK(h, hipMemcpyAsync(h->stage_d, h->stage_h, in_bytes, hipMemcpyHostToDevice, stream));
+	char *d = h->stage_d;
+	rc = hoqp_wbc_dynamics_batched(h, model, batch, (const double *)(d + iq), (const double *)(d + iu), include_gravity,
+				       (double *)(d + oM), (double *)(d + oh), (double *)(d + oJf), (double *)(d + oJd),
+				       (double *)(d + ofp), Jb ? (double *)(d + oJb) : nullptr, stream);
+	if (rc)
+		return rc;
+	HIP_OK(h, hipMemcpyAsync(h->stage_h + in_bytes, h->stage_d + in_bytes, st.size - in_bytes, hipMemcpyDeviceToHost, stream));
+	HIP_OK(h, hipStreamSynchronize(stream));
+	const char *s = h->stage_h;
+	std::memcpy(M, s + oM, 8 * B * 324);
+	std::memcpy(hvec, s + oh, 8 * B * 18);
+	std::memcpy(Jfoot, s + oJf, 8 * B * 216);
+	std::memcpy(Jdotu, s + oJd, 8 * B * 12);
+	std::memcpy(footpos, s + ofp, 8 * B * 12);
+	if (Jb)
+		std::memcpy(Jb, s + oJb, 8 * B * 108);
 	return 0;
 }
 
@@ -1065,7 +1162,7 @@ extern "C" int hoqp_synchronize(hoqp_handle *h, void *stream)
 {
 	if (!h)
 		return -1;
-	HIP_OK(h, hipSetDevice(h->cfg.device));
+	ENTER_DEVICE(h);
 	HIP_OK(h, hipStreamSynchronize((hipStream_t)stream));
 	return 0;
 }
@@ -1074,7 +1171,7 @@ extern "C" int hoqp_kernel_time_ms(hoqp_handle *h, int reset, double *avg_ms, in
 {
 	if (!h)
 		return -1;
-	HIP_OK(h, hipSetDevice(h->cfg.device));
+	ENTER_DEVICE(h);
 	double tot = 0.0;
 	int cnt = 0;
 	for (auto &e : h->ev) {
@@ -1103,7 +1200,7 @@ extern "C" int hoqp_selftest(hoqp_handle *h)
 {
 	if (!h)
 		return -1;
-	HIP_OK(h, hipSetDevice(h->cfg.device));
+	ENTER_DEVICE(h);
 	int *d = nullptr, host = 0;
 	HIP_OK(h, hipMalloc(&d, sizeof(int)));
 	HIP_OK(h, hipMemset(d, 0, sizeof(int)));

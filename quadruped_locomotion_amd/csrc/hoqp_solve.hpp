@@ -13,6 +13,7 @@
 
 #include "../../include/hoqp.h"
 #include "hoqp_device.hpp"
+#include "wbc_tasks.hpp"
 
 namespace hoqp {
 
@@ -43,12 +44,17 @@ struct SolveArgs {
 	int use_bl;	   // some level needs its equality rows inside the active-set loop
 	int any_hard;	   // some level looks at rows stored by an earlier level
 	int last_ineq_use; // last level that looks at stored inequality rows (rows are dropped after it)
+	// fused WBC entry (hoqp_solve_kernel<.., .., true>): the task blocks are generated from the
+	// dynamics terms (wbc_tasks.hpp) instead of being read from A / b / D / f
+	hoqp_wbc_inputs win;
+	WbcPrm wprm;
+	double *qdd, *tau;  // [batch][12] outputs of the fused tail (may be null)
 	unsigned long long *dbg;  // HOQP_PROFILE builds only: [batch][16] cycle stamps per section
 };
 
 // byte offsets of the LDS arrays (shared by host sizing and device addressing)
 struct LdsOff {
-	int Z, x, G, g, vs, s, c, TV, S, BL, r0, rho, a0, tau, rdiag, rhs, X, tmp, dump, pivlane, W, xlane, colpos, vlist, total;
+	int Z, x, G, g, vs, s, c, TV, S, BL, r0, rho, a0, tau, rdiag, rhs, X, tmp, dump, b3, pivlane, W, xlane, colpos, vlist, total;
 };
 
 __host__ __device__ inline LdsOff lds_offsets(const SolveArgs &a)
@@ -81,6 +87,7 @@ __host__ __device__ inline LdsOff lds_offsets(const SolveArgs &a)
 	o.X = o.S;  // the staging buffer is dead whenever X is live
 	o.tmp = take(8 * kWave);
 	o.dump = take(8 * kWave);  // per-lane sink of predicated-off stores
+	o.b3 = take(8 * 24);	   // fused WBC entry: right-hand side of the tracking level
 	o.pivlane = take(4 * NR);
 	o.W = take(4 * NR);
 	o.xlane = take(4 * XROWS);
@@ -92,7 +99,7 @@ __host__ __device__ inline LdsOff lds_offsets(const SolveArgs &a)
 
 #ifdef __HIP_DEVICE_COMPILE__
 struct Lds {
-	ldsd *Z, *x, *G, *g, *vs, *s, *c, *TV, *S, *BL, *r0, *rho, *a0, *tau, *rdiag, *rhs, *X, *tmp, *dump;
+	ldsd *Z, *x, *G, *g, *vs, *s, *c, *TV, *S, *BL, *r0, *rho, *a0, *tau, *rdiag, *rhs, *X, *tmp, *dump, *b3;
 	ldsi *pivlane, *W, *xlane, *colpos, *vlist;
 };
 
@@ -119,6 +126,7 @@ __device__ __forceinline__ Lds lds_bind(const SolveArgs &a, HOQP_LDS char *base)
 	l.X = (ldsd *)(base + o.X);
 	l.tmp = (ldsd *)(base + o.tmp);
 	l.dump = (ldsd *)(base + o.dump);
+	l.b3 = (ldsd *)(base + o.b3);
 	l.pivlane = (ldsi *)(base + o.pivlane);
 	l.W = (ldsi *)(base + o.W);
 	l.xlane = (ldsi *)(base + o.xlane);
@@ -882,7 +890,7 @@ __device__ __forceinline__ void project_task(const double *__restrict__ rows_g, 
 		wave_sync();  // readers of the previous chunk are done with S
 #pragma unroll
 		for (int t = 0; t < CHUNK / 2; ++t)
-			l.S[(2 * t + h) * SROW + c] = pre[t];
+			l.S[(2 * t + h) * SROW + c] = sel(c < n, pre[t]);  // storage columns >= n are not part of the problem
 		const double rv = rv_next;
 		wave_sync();
 		if (r0 + CHUNK < rows)
@@ -970,33 +978,35 @@ __device__ __forceinline__ void load_bm(double (&bm)[NR / 4][2], int n, int nz, 
 	}
 }
 
-__device__ __forceinline__ void project_task_mfma(const double *__restrict__ rows_g, const double *__restrict__ rhs_g,
-						  int rows, int nstore, int nz, int ld, const double (&bm)[NR / 4][2],
-						  bool to_T, int P, const Lds &l)
-{
-	const int lane = lane_id();
-	const int j16 = lane & 15, q4 = lane >> 4;
-	const bool two = nz + 1 > 16;  // second block of 16 output columns needed
-	// The A operand of the 16x16x4 tile is A[i = lane % 16][k = lane / 16]: each lane loads its own
-	// entries straight from the task rows (16 rows x 32 contiguous bytes per load instruction); the
-	// next chunk's loads are in flight during the multiply.
+// Where the matrix-core operand of a task chunk comes from.  fetch() issues the loads of one
+// chunk of 16 rows (the next chunk's loads are in flight during the multiply), take() waits for
+// them and forms the operand: A[i = lane % 16][k = lane / 16 + 4 kb] and the right-hand sides of
+// rows lane / 16 + 4 r.
+//
+// TaskRowsSrc: the rows of a stored task block (generic entry), each lane loading its own entries
+// straight from global memory (16 rows x 32 contiguous bytes per load instruction).
+struct TaskRowsSrc {
+	const double *__restrict__ rows_g;
+	const double *__restrict__ rhs_g;
+	int nstore, n;
 	double pre[NR / 4], rpre[4];
-	auto fetch = [&](int r0) {
+	__device__ __forceinline__ void fetch(int r0, int rows)
+	{
+		const int lane = lane_id(), j16 = lane & 15, q4 = lane >> 4;
 		const int nr = min(CHUNK, rows - r0);
 		const double *row = rows_g + (size_t)(r0 + (j16 < nr ? j16 : 0)) * nstore;
 #pragma unroll
 		for (int kb = 0; kb < NR / 4; ++kb) {
 			const int k = 4 * kb + q4;
-			pre[kb] = row[k < nstore ? k : 0];  // bm is zero for k >= n
+			pre[kb] = row[k < nstore ? k : 0];
 		}
 #pragma unroll
 		for (int r = 0; r < 4; ++r)
 			rpre[r] = rhs_g[r0 + (q4 + 4 * r < nr ? q4 + 4 * r : 0)];
-	};
-	fetch(0);
-	for (int r0 = 0; r0 < rows; r0 += CHUNK) {
-		const int nr = min(CHUNK, rows - r0);
-		double av[NR / 4], rvr[4];
+	}
+	__device__ __forceinline__ void take(double (&av)[NR / 4], double (&rvr)[4])
+	{
+		const int q4 = lane_id() >> 4;
 #pragma unroll
 		for (int kb = 0; kb < NR / 4; ++kb)
 			av[kb] = pre[kb];
@@ -1009,8 +1019,84 @@ __device__ __forceinline__ void project_task_mfma(const double *__restrict__ row
 #pragma unroll
 		for (int r = 0; r < 4; ++r)
 			pin(rvr[r]);
+		// columns >= n of the storage are not part of the instance's problem: whatever they hold
+		// (NaN included) must not reach the product
+#pragma unroll
+		for (int kb = 0; kb < NR / 4; ++kb)
+			av[kb] = sel(4 * kb + q4 < n, av[kb]);
+	}
+};
+
+// WbcLevelSrc: level LEVEL of the WBC hierarchy generated from the dynamics terms (fused entry).
+template <int LEVEL>
+struct WbcLevelSrc {
+	const WbcCtx &x;
+	const WbcPrm &prm;
+	const Lds &l;
+	const int (&jc)[NR / 4];  // wbc_jcoff of this lane's columns
+	double lv[NR / 4], sc[NR / 4], ad[NR / 4], rl[4], rs[4], ra[4];
+	__device__ __forceinline__ WbcLevelSrc(const WbcCtx &x_, const WbcPrm &prm_, const Lds &l_, const int (&jc_)[NR / 4])
+		: x(x_), prm(prm_), l(l_), jc(jc_)
+	{
+	}
+	__device__ __forceinline__ void fetch(int r0, int rows)
+	{
+		const int lane = lane_id(), j16 = lane & 15, q4 = lane >> 4;
+		const int nr = min(CHUNK, rows - r0);
+		const int r = r0 + (j16 < nr ? j16 : 0);
+#pragma unroll
+		for (int kb = 0; kb < NR / 4; ++kb) {
+			const Entry e = wbc_entry<LEVEL>(x, prm, r, 4 * kb + q4, jc[kb]);
+			lv[kb] = *e.p;
+			sc[kb] = e.scale;
+			ad[kb] = e.add;
+		}
+#pragma unroll
+		for (int rr = 0; rr < 4; ++rr) {
+			const int ri = r0 + (q4 + 4 * rr < nr ? q4 + 4 * rr : 0);
+			if (LEVEL == 3) {
+				rl[rr] = l.b3[ri];
+				rs[rr] = 1.0;
+				ra[rr] = 0.0;
+			} else {
+				const Entry e = wbc_rhs_entry<LEVEL>(x, prm, ri);
+				rl[rr] = *e.p;
+				rs[rr] = e.scale;
+				ra[rr] = e.add;
+			}
+		}
+	}
+	__device__ __forceinline__ void take(double (&av)[NR / 4], double (&rvr)[4])
+	{
+#pragma unroll
+		for (int kb = 0; kb < NR / 4; ++kb)
+			pin(lv[kb]);
+#pragma unroll
+		for (int r = 0; r < 4; ++r)
+			pin(rl[r]);
+#pragma unroll
+		for (int kb = 0; kb < NR / 4; ++kb)
+			av[kb] = (sc[kb] != 0.0) ? sc[kb] * lv[kb] : ad[kb];
+#pragma unroll
+		for (int r = 0; r < 4; ++r)
+			rvr[r] = fma(rs[r], rl[r], ra[r]);
+	}
+};
+
+template <typename Src>
+__device__ __forceinline__ void project_task_mfma(Src &src, int rows, int nz, int ld, const double (&bm)[NR / 4][2],
+						  bool to_T, int P, const Lds &l)
+{
+	const int lane = lane_id();
+	const int j16 = lane & 15, q4 = lane >> 4;
+	const bool two = nz + 1 > 16;  // second block of 16 output columns needed
+	src.fetch(0, rows);
+	for (int r0 = 0; r0 < rows; r0 += CHUNK) {
+		const int nr = min(CHUNK, rows - r0);
+		double av[NR / 4], rvr[4];
+		src.take(av, rvr);
 		if (r0 + CHUNK < rows)
-			fetch(r0 + CHUNK);
+			src.fetch(r0 + CHUNK, rows);
 		d4v acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
 		if (two) {
 #pragma unroll
@@ -1274,8 +1360,10 @@ __device__ __forceinline__ void level_update_t(const Lds &l, int n, int Pg, int 
 // HARD: some level of the hierarchy looks at rows stored by an earlier level (false for a single
 // inequality level under GATE, i.e. the reference's WBC hierarchy: no hard rows, no working set,
 // no phase 1, no multipliers -- all of that code is compiled out).
-template <bool GATE, bool HARD>
-__device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, LevelState &st, int inst, int k, int m, int p)
+// WBC: the task rows come from the generator of wbc_tasks.hpp (fused entry) instead of a.A / a.D.
+template <bool GATE, bool HARD, bool WBC>
+__device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, LevelState &st, int inst, int k, int m, int p,
+					    const WbcCtx &wx, const int (&jc)[NR / 4])
 {
 	const int lane = lane_id(), s = lane & 3, c = lane >> 2;
 	const int n = uni(st.n), ld = a.ld;
@@ -1307,15 +1395,40 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 	// ---- 1. project the task into the current null space (ConstructH/C/D/FVector,
 	//         ho_qp_problem.cpp:180-285, in factored form) ----
 	auto project = [&](bool doA, bool doD) {
-		if (nz < 32) {  // matrix-core path
+		if (WBC) {  // fused entry (n <= 30: always the matrix-core path)
 			double bm[NR / 4][2];
 			load_bm(bm, n, nz, ld, l);
-			if (m > 0 && doA)
-				project_task_mfma(a.A[k] + (size_t)inst * a.m[k] * nstore, a.b[k] + (size_t)inst * a.m[k], m,
-						  nstore, nz, ld, bm, true, 0, l);
-			if (p > 0 && doD)
-				project_task_mfma(a.D[k] + (size_t)inst * a.p[k] * nstore, a.f[k] + (size_t)inst * a.p[k], p,
-						  nstore, nz, ld, bm, false, P, l);
+			if (k == 1) {
+				if (p > 0 && doD) {
+					WbcLevelSrc<1> src(wx, a.wprm, l, jc);
+					project_task_mfma(src, p, nz, ld, bm, false, P, l);
+				}
+			} else if (m > 0 && doA) {
+				if (k == 0) {
+					WbcLevelSrc<0> src(wx, a.wprm, l, jc);
+					project_task_mfma(src, m, nz, ld, bm, true, 0, l);
+				} else if (k == 2) {
+					WbcLevelSrc<2> src(wx, a.wprm, l, jc);
+					project_task_mfma(src, m, nz, ld, bm, true, 0, l);
+				} else if (k == 3) {
+					WbcLevelSrc<3> src(wx, a.wprm, l, jc);
+					project_task_mfma(src, m, nz, ld, bm, true, 0, l);
+				} else {
+					WbcLevelSrc<4> src(wx, a.wprm, l, jc);
+					project_task_mfma(src, m, nz, ld, bm, true, 0, l);
+				}
+			}
+		} else if (nz < 32) {  // matrix-core path
+			double bm[NR / 4][2];
+			load_bm(bm, n, nz, ld, l);
+			if (m > 0 && doA) {
+				TaskRowsSrc src = {a.A[k] + (size_t)inst * a.m[k] * nstore, a.b[k] + (size_t)inst * a.m[k], nstore, n};
+				project_task_mfma(src, m, nz, ld, bm, true, 0, l);
+			}
+			if (p > 0 && doD) {
+				TaskRowsSrc src = {a.D[k] + (size_t)inst * a.p[k] * nstore, a.f[k] + (size_t)inst * a.p[k], nstore, n};
+				project_task_mfma(src, p, nz, ld, bm, false, P, l);
+			}
 		} else {
 			double zc[NR];
 			const ProjLane pl = proj_lane(nz);
@@ -1568,7 +1681,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 	auto q3_delta = [&]() {
 		int off = 0, myoff = 0, myp = 0;
 		for (int j = 0; j < k; ++j) {
-			const int pj = uni(a.p_inst ? a.p_inst[(size_t)inst * a.L + j] : a.p[j]);
+			const int pj = WBC ? wbc_p(wx, j) : uni(a.p_inst ? a.p_inst[(size_t)inst * a.L + j] : a.p[j]);
 			if (lane >= off && lane < off + pj) {
 				myoff = off;
 				myp = pj;
@@ -1854,12 +1967,14 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 		// one row per lane: x += (Z y), g -= (G y) with the slack bookkeeping of this level's rows
 		if (lane < n)
 			l.x[lane] += l.S[lane];
+		bool nonfinite = !isfinite(level_res2);
 		const double dq = q3 ? q3_delta() : 0.0;  // stored g goes back to each row's own slack
 		if (lane < Pg) {
 			double gi = l.g[lane] - l.S[n + lane] - dq;
 			if (lane >= P) {
 				// v* = (D x - f)_+ ; the row becomes hard with rhs f + v* - D x
 				const double vopt = fmax(0.0, -gi);
+				nonfinite |= !isfinite(gi);
 				l.vs[lane] = vopt;
 				if (a.out.v)
 					a.out.v[(size_t)inst * a.Ptot + st.Pout + (lane - P)] = vopt;
@@ -1867,6 +1982,8 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 			}
 			l.g[lane] = gi;
 		}
+		if (__ballot(nonfinite))
+			st.status |= HOQP_STATUS_NONFINITE;
 	}
 	if (lane == 0) {
 		if (a.out.level_res)
@@ -1897,7 +2014,181 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 
 #endif  // __HIP_DEVICE_COMPILE__
 
-template <bool GATE, bool HARD>
+#ifdef __HIP_DEVICE_COMPILE__
+// ---------------------------------------------------------------------------
+// Tail of the fused WBC entry: CalcJointTorquesCmd (ho_qp_controller.cpp:67-73), q_j_ddot (:23) and
+// the five CheckSolutionValid results (:18-22, helper_functions.hpp:63-91) at the final x, from the
+// dynamics terms themselves instead of the 76 generated task rows:
+//   w  = M udd - J_c' lam + h :  rows 0..5 = residual of the floating-base EoM (level 0),
+//                                rows 6..17 = tau; the torque rows of level 1 are tau - tau_max, tau_min - tau
+//   jv = J_foot udd           :  contact feet + J_c_dot u = level 2, swing feet - b = level 3
+// One row per quad (lane s of the quad takes entries s, s + 4, ...), then one row per lane.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void wbc_tail(const SolveArgs &a, const Lds &l, const WbcCtx &wx, int inst, int &status)
+{
+	const int lane = lane_id(), s = lane & 3, c = lane >> 2;
+	const WbcPrm &prm = a.wprm;
+	ldsd *lamf = l.TV, *wv = l.TV + 16, *jv = l.TV + 40, *jb = l.TV + 56;  // the reflector store is dead here
+	// contact force per foot row (zero for swing legs)
+	if (lane < 12) {
+		const int leg = lane / 3, d = lane - 3 * leg;
+		int slot = -1;
+#pragma unroll
+		for (int i = 0; i < 4; ++i)
+			slot = (i < wx.nc && wbc_pick(wx.clp, i) == leg) ? i : slot;
+		lamf[lane] = (slot >= 0) ? l.x[kNU + 3 * (slot >= 0 ? slot : 0) + d] : 0.0;
+	}
+	wave_sync();
+	double xq[5], lq[3];
+#pragma unroll
+	for (int t = 0; t < 5; ++t)
+		xq[t] = l.x[(s + 4 * t < kNU) ? s + 4 * t : 0];
+#pragma unroll
+	for (int t = 0; t < 3; ++t)
+		lq[t] = lamf[s + 4 * t];
+#pragma unroll
+	for (int t = 0; t < 5; ++t)
+		pin(xq[t]);
+#pragma unroll
+	for (int t = 0; t < 3; ++t)
+		pin(lq[t]);
+#pragma unroll
+	for (int t = 0; t < 5; ++t)
+		xq[t] = sel(s + 4 * t < kNU, xq[t]);
+	// w (18 rows, two passes) and jv (12 rows) and, with a general J_b, J_b udd (6 rows)
+	double mv[2][5], jt[2][3], jr[5], br[5], hv[2];
+	const int rowj = (c < 12) ? c : 0, rowb = (c < 6) ? c : 0;
+#pragma unroll
+	for (int ps = 0; ps < 2; ++ps) {
+		const int i = c + 16 * ps;
+		const int ic = (i < kNU) ? i : 0;
+#pragma unroll
+		for (int t = 0; t < 5; ++t)
+			mv[ps][t] = wx.M[ic * kNU + ((s + 4 * t < kNU) ? s + 4 * t : 0)];
+#pragma unroll
+		for (int t = 0; t < 3; ++t)
+			jt[ps][t] = wx.Jf[(s + 4 * t) * kNU + ic];
+		hv[ps] = wx.h[ic];
+	}
+#pragma unroll
+	for (int t = 0; t < 5; ++t)
+		jr[t] = wx.Jf[rowj * kNU + ((s + 4 * t < kNU) ? s + 4 * t : 0)];
+	if (wx.Jb) {
+#pragma unroll
+		for (int t = 0; t < 5; ++t)
+			br[t] = wx.Jb[rowb * kNU + ((s + 4 * t < kNU) ? s + 4 * t : 0)];
+	}
+#pragma unroll
+	for (int ps = 0; ps < 2; ++ps) {
+		const int i = c + 16 * ps;
+		double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+		for (int t = 0; t < 5; ++t) {
+			if (t & 1)
+				d1 = fma(mv[ps][t], xq[t], d1);  // xq == 0 beyond column 17
+			else
+				d0 = fma(mv[ps][t], xq[t], d0);
+		}
+#pragma unroll
+		for (int t = 0; t < 3; ++t)
+			d1 = fma(-jt[ps][t], lq[t], d1);
+		const double w = quad_sum(d0 + d1) + hv[ps];
+		if (i < kNU && s == 0)
+			wv[i] = w;
+	}
+	{
+		double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+		for (int t = 0; t < 5; ++t) {
+			if (t & 1)
+				d1 = fma(jr[t], xq[t], d1);
+			else
+				d0 = fma(jr[t], xq[t], d0);
+		}
+		const double d = quad_sum(d0 + d1);
+		if (c < 12 && s == 0)
+			jv[c] = d;
+	}
+	if (wx.Jb) {
+		double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+		for (int t = 0; t < 5; ++t) {
+			if (t & 1)
+				d1 = fma(br[t], xq[t], d1);
+			else
+				d0 = fma(br[t], xq[t], d0);
+		}
+		const double d = quad_sum(d0 + d1);
+		if (c < 6 && s == 0)
+			jb[c] = d;
+	} else if (lane < 6) {
+		jb[lane] = l.x[lane];  // J_b = [I6 0]
+	}
+	wave_sync();
+	// ---- one row per lane ----
+	const double wl = wv[lane < kNU ? lane : 0];
+	if (lane >= kNB && lane < kNU) {
+		if (a.tau)
+			a.tau[(size_t)inst * kNJ + lane - kNB] = wl;
+		if (a.qdd)
+			a.qdd[(size_t)inst * kNJ + lane - kNB] = l.x[lane];
+	}
+	if (__ballot(lane < kNU && !isfinite(wl)))
+		status |= HOQP_STATUS_NONFINITE;
+	if (!(a.out.flags || a.out.eq_res_max || a.out.ineq_viol_max || a.out.active_mask))
+		return;
+	const int m2 = 3 * wx.nc, m3 = 6 + 3 * wx.ns, p1 = 2 * kNJ + 4 * wx.nc;
+	// level 0
+	const double er0 = wave_max(lane < kNB ? fabs(wl) : 0.0);
+	// level 1: torque rows from tau, friction rows from x (Q1: columns 6 + 3 leg)
+	double d1v = -1e300;
+	if (lane < kNJ) {
+		d1v = wv[kNB + lane] - prm.tau_max;
+	} else if (lane < 2 * kNJ) {
+		d1v = prm.tau_min - wv[kNB + lane - kNJ];
+	} else if (lane < p1) {
+		const int i = (lane - 2 * kNJ) >> 2, t = (lane - 2 * kNJ) & 3;
+		const int col = prm.friction_quirk ? kNB + wbc_pick(wx.clp, i) * 3 : kNU + 3 * i;
+		const double xa = l.x[col + (t >> 1)], xz = l.x[col + 2];
+		d1v = fma(-prm.mu, xz, (t & 1) ? -xa : xa);
+	}
+	const double iv1 = wave_max(lane < p1 ? d1v : -1e300);
+	const unsigned long long act = __ballot(lane < p1 && d1v >= -1e-7);
+	// level 2
+	double e2 = 0.0;
+	if (lane < m2) {
+		const int fr = wbc_crow(wx, lane);
+		e2 = fabs(jv[fr] + wx.Jdu[fr]);
+	}
+	const double er2 = wave_max(e2);
+	// level 3
+	double e3 = 0.0;
+	if (lane < 6) {
+		const int rb = (lane < 3) ? 3 + lane : lane - 3;
+		e3 = fabs(jb[rb] - l.b3[lane]);
+	} else if (lane < m3) {
+		e3 = fabs(jv[wbc_srow(wx, lane - 6)] - l.b3[lane]);
+	}
+	const double er3 = wave_max(e3);
+	// level 4
+	const double er4 = wave_max(lane < m2 ? fabs(l.x[kNU + (lane < m2 ? lane : 0)]) : 0.0);
+	if (lane < 5) {
+		const double er = lane == 0 ? er0 : (lane == 2 ? er2 : (lane == 3 ? er3 : (lane == 4 ? er4 : 0.0)));
+		const double iv = lane == 1 ? iv1 : 0.0;
+		const size_t o = (size_t)inst * 5 + lane;
+		if (a.out.flags)
+			a.out.flags[o] = (er <= 1e-7 && (lane != 1 || iv <= 0.0)) ? 1 : 0;
+		if (a.out.eq_res_max)
+			a.out.eq_res_max[o] = er;
+		if (a.out.ineq_viol_max)
+			a.out.ineq_viol_max[o] = iv;
+	}
+	if (lane == 0 && a.out.active_mask)
+		a.out.active_mask[inst] = act;
+}
+#endif  // __HIP_DEVICE_COMPILE__
+
+template <bool GATE, bool HARD, bool WBC>
 __global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
 {
 #ifdef __HIP_DEVICE_COMPILE__
@@ -1908,11 +2199,31 @@ __global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
 	if (inst >= a.batch)
 		return;
 	LevelState st;
-	st.n = uni(a.n_inst ? a.n_inst[inst] : a.n);
+	st.status = 0;
+	WbcCtx wx = {};
+	int jc[NR / 4] = {-1, -1, -1, -1, -1, -1, -1, -1};
+	if (WBC) {
+		wx = wbc_ctx(a.win, inst);
+		wx.clp = uni(wx.clp);
+		wx.slp = uni(wx.slp);
+		wx.nc = uni(wx.nc);
+		wx.ns = uni(wx.ns);
+		wx.n = uni(wx.n);
+#pragma unroll
+		for (int kb = 4; kb < NR / 4; ++kb)
+			jc[kb] = wbc_jcoff(wx, 4 * kb + (lane >> 4));
+		st.n = wx.n;
+	} else {
+		// per-instance extents are device data: clamp them to the storage extents (a larger value
+		// would run past the LDS arrays and into the next instance's rows) and report it
+		const int ni = uni(a.n_inst ? a.n_inst[inst] : a.n);
+		st.n = min(max(ni, 1), a.n);
+		if (st.n != ni)
+			st.status |= HOQP_STATUS_BAD_EXTENT;
+	}
 	st.nz = st.n;
 	st.P = 0;
 	st.Pout = 0;
-	st.status = 0;
 	st.t_last = __builtin_amdgcn_s_memtime();
 	const int n = st.n, ld = a.ld;
 	// InitPrevProblemValuesToDefault, ho_qp_problem.cpp:119-128:  Z = I, x = 0
@@ -1932,16 +2243,30 @@ __global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
 	}
 	if (lane < NR)
 		l.x[lane] = 0.0;
+	if (WBC && lane < 24)
+		l.b3[lane] = wbc_rhs3(wx, a.wprm, lane);
 	if (a.out.v)
 		for (int i = lane; i < a.Ptot; i += kWave)
 			a.out.v[(size_t)inst * a.Ptot + i] = 0.0;
 	wave_sync();
 
 	HOQP_STAMP(0);
+	int pseen = 0;
 	for (int k = 0; k < a.L; ++k) {
-		int m = uni(a.m_inst ? a.m_inst[(size_t)inst * a.L + k] : a.m[k]);
-		int p = uni(a.p_inst ? a.p_inst[(size_t)inst * a.L + k] : a.p[k]);
-		solve_level<GATE, HARD>(a, l, st, inst, k, m, p);
+		int m, p;
+		if (WBC) {
+			m = wbc_m(wx, k);
+			p = wbc_p(wx, k);
+		} else {
+			const int mi = uni(a.m_inst ? a.m_inst[(size_t)inst * a.L + k] : a.m[k]);
+			const int pi = uni(a.p_inst ? a.p_inst[(size_t)inst * a.L + k] : a.p[k]);
+			m = min(max(mi, 0), a.m[k]);
+			p = min(max(pi, 0), a.p[k]);
+			if (m != mi || p != pi)
+				st.status |= HOQP_STATUS_BAD_EXTENT;
+			pseen += p;
+		}
+		solve_level<GATE, HARD, WBC>(a, l, st, inst, k, m, p, wx, jc);
 	}
 
 	// ---- final x and the CheckSolutionValid flags (helper_functions.hpp:63-91) ----
@@ -1950,7 +2275,9 @@ __global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
 		st.status |= HOQP_STATUS_NONFINITE;
 	if (a.out.x && lane < a.n)
 		a.out.x[(size_t)inst * a.n + lane] = xi;
-	if (a.out.flags || a.out.eq_res_max || a.out.ineq_viol_max || a.out.active_mask) {
+	if (WBC) {
+		wbc_tail(a, l, wx, inst, st.status);
+	} else if (a.out.flags || a.out.eq_res_max || a.out.ineq_viol_max || a.out.active_mask) {
 		// one task row per quad (row = 16 * pass + c, lane s of the quad takes entries s, s+4, ...):
 		// every load instruction covers 16 rows x 32 contiguous bytes instead of 64 rows x 8 bytes
 		const int s = lane & 3, c = lane >> 2;
@@ -1968,6 +2295,7 @@ __global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
 		// value (inequalities) and, for inequalities, the bit mask of rows with value >= -1e-7
 		auto check_rows = [&](const double *rows_g, const double *rhs_g, int cnt, bool ineq, unsigned long long *act) {
 			double mx = ineq ? -1e300 : 0.0;
+			bool bad = false;
 			unsigned long long bits = 0ull;
 			for (int r0 = 0; r0 < cnt; r0 += 16) {
 				const int r = r0 + c;
@@ -1981,12 +2309,14 @@ __global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
 				double d0 = 0.0, d1 = 0.0;
 #pragma unroll
 				for (int t = 0; t < NT; t += 2) {
-					d0 = fma(tv[t], xq[t], d0);  // xq == 0 beyond n
-					d1 = fma(tv[t + 1], xq[t + 1], d1);
+					// storage columns >= n are not part of the problem (they may hold anything)
+					d0 = fma(sel(s + 4 * t < n, tv[t]), xq[t], d0);
+					d1 = fma(sel(s + 4 * t + 4 < n, tv[t + 1]), xq[t + 1], d1);
 				}
 				const double d = quad_sum(d0 + d1) - rh;
 				const double e = ineq ? d : fabs(d);
 				mx = valid ? fmax(mx, e) : mx;
+				bad |= valid && !isfinite(e);  // fmax drops a NaN: keep it visible
 				if (ineq) {
 					const int pred = valid && e >= -1e-7;
 					const int mine = __shfl(pred, (lane * 4) & (kWave - 1));  // lane q < 16 <- quad q
@@ -1997,13 +2327,14 @@ __global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
 			}
 			if (act)
 				*act = bits;
-			return wave_max(mx);
+			const double wm = wave_max(mx);
+			return __ballot(bad) ? __builtin_nan("") : wm;
 		};
 		unsigned long long amask = 0ull;
 		int prow = 0;
 		for (int k = 0; k < a.L; ++k) {
-			const int m = uni(a.m_inst ? a.m_inst[(size_t)inst * a.L + k] : a.m[k]);
-			const int p = uni(a.p_inst ? a.p_inst[(size_t)inst * a.L + k] : a.p[k]);
+			const int m = min(max(uni(a.m_inst ? a.m_inst[(size_t)inst * a.L + k] : a.m[k]), 0), a.m[k]);
+			const int p = min(max(uni(a.p_inst ? a.p_inst[(size_t)inst * a.L + k] : a.p[k]), 0), a.p[k]);
 			double er = 0.0, iv = -1e300;
 			if (m > 0)
 				er = check_rows(a.A[k] + (size_t)inst * a.m[k] * a.n, a.b[k] + (size_t)inst * a.m[k], m, false, nullptr);
@@ -2016,13 +2347,16 @@ __global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
 			prow += p;
 			if (lane == 0) {
 				size_t o = (size_t)inst * a.L + k;
+				// a NaN residual is "violated", not "valid"
 				if (a.out.flags)
-					a.out.flags[o] = (!(er > 1e-7) && !(p > 0 && iv > 0.0)) ? 1 : 0;
+					a.out.flags[o] = (er <= 1e-7 && !(p > 0 && !(iv <= 0.0))) ? 1 : 0;
 				if (a.out.eq_res_max)
 					a.out.eq_res_max[o] = er;
 				if (a.out.ineq_viol_max)
 					a.out.ineq_viol_max[o] = p ? iv : 0.0;
 			}
+			if (!isfinite(er) || (p > 0 && !isfinite(iv)))
+				st.status |= HOQP_STATUS_NONFINITE;
 		}
 		if (lane == 0 && a.out.active_mask)
 			a.out.active_mask[inst] = amask;

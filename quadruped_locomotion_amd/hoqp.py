@@ -29,10 +29,12 @@ STATUS_MAX_ITER = 0x01
 STATUS_INFEASIBLE_START = 0x02
 STATUS_WORKSPACE = 0x04
 STATUS_NONFINITE = 0x08
+STATUS_BAD_EXTENT = 0x20
 
 EXPORTS = (
     "hoqp_default_config", "hoqp_create", "hoqp_destroy", "hoqp_last_error_string",
     "hoqp_solve_tasks_batched", "hoqp_solve_wbc_batched", "hoqp_solve_tasks_host", "hoqp_solve_wbc_host",
+    "hoqp_solve_wbc_unfused", "hoqp_wbc_build_tasks_batched",
     "hoqp_default_quadruped_model", "hoqp_wbc_dynamics_batched", "hoqp_wbc_dynamics_host", "hoqp_wbc_poststep_batched",
     "hoqp_default_gait", "hoqp_gait_sample_batched", "hoqp_standup_sample_batched",
     "hoqp_base_walk_sample_batched", "hoqp_synchronize",
@@ -116,6 +118,10 @@ def load_library():
         lib.hoqp_last_error_string.restype = C.c_char_p
         lib.hoqp_solve_tasks_batched.argtypes = [C.c_void_p, C.POINTER(TaskBatch), C.POINTER(ResultBatch), C.c_void_p]
         lib.hoqp_solve_wbc_batched.argtypes = [C.c_void_p, C.POINTER(WbcInputs), C.POINTER(WbcOutputs), C.c_void_p]
+        lib.hoqp_solve_wbc_unfused.argtypes = lib.hoqp_solve_wbc_batched.argtypes
+        lib.hoqp_solve_wbc_host.argtypes = [C.c_void_p, C.POINTER(WbcInputs), C.POINTER(WbcOutputs)]
+        lib.hoqp_solve_tasks_host.argtypes = [C.c_void_p, C.POINTER(TaskBatch), C.POINTER(ResultBatch)]
+        lib.hoqp_wbc_build_tasks_batched.argtypes = [C.c_void_p, C.POINTER(WbcInputs), C.POINTER(TaskBatch), C.c_void_p]
         lib.hoqp_synchronize.argtypes = [C.c_void_p, C.c_void_p]
         lib.hoqp_default_quadruped_model.argtypes = [C.POINTER(QuadrupedModel)]
         lib.hoqp_default_quadruped_model.restype = None
@@ -383,11 +389,10 @@ class HoQpSolver:
                     "hoqp_base_walk_sample_batched")
         return base_cmd
 
-    def solve_wbc(self, dinp, out=None):
+    def _wbc_inputs(self, dinp):
         t = self.torch
-        B = dinp["M"].shape[0]
         wi = WbcInputs()
-        wi.batch = B
+        wi.batch = dinp["M"].shape[0]
         for name in ("M", "h", "Jfoot", "Jdotu", "footpos", "Jb", "q", "u", "base_cmd", "leg_cmd"):
             arr = dinp.get(name)
             if arr is not None:
@@ -396,12 +401,46 @@ class HoQpSolver:
         c = dinp["contact"]
         assert c.dtype == t.int32 and c.is_contiguous() and c.is_cuda
         wi.contact = c.data_ptr()
+        return wi
+
+    def build_wbc_tasks(self, dinp):
+        """The five task blocks of every state as dense device tensors (hoqp_wbc_build_tasks_batched):
+        returns (tasks, n_inst, m_inst, p_inst) in the form solve_tasks takes."""
+        t = self.torch
+        B = dinp["M"].shape[0]
+        wi = self._wbc_inputs(dinp)
+        kw = dict(dtype=t.float64, device=self.device)
+        tasks = []
+        tb = TaskBatch()
+        tb.batch, tb.n, tb.num_levels = B, 30, 5
+        for k, (m, p) in enumerate(zip(WBC_M, WBC_P)):
+            task = {}
+            tb.m[k], tb.p[k] = m, p
+            if m:
+                task["A"], task["b"] = t.full((B, m, 30), float("nan"), **kw), t.full((B, m), float("nan"), **kw)
+                tb.A[k], tb.b[k] = task["A"].data_ptr(), task["b"].data_ptr()
+            if p:
+                task["D"], task["f"] = t.full((B, p, 30), float("nan"), **kw), t.full((B, p), float("nan"), **kw)
+                tb.D[k], tb.f[k] = task["D"].data_ptr(), task["f"].data_ptr()
+            tasks.append(task)
+        n_inst = t.zeros(B, dtype=t.int32, device=self.device)
+        m_inst = t.zeros(B, 5, dtype=t.int32, device=self.device)
+        p_inst = t.zeros(B, 5, dtype=t.int32, device=self.device)
+        tb.n_inst, tb.m_inst, tb.p_inst = n_inst.data_ptr(), m_inst.data_ptr(), p_inst.data_ptr()
+        self._check(self.lib.hoqp_wbc_build_tasks_batched(self.h, C.byref(wi), C.byref(tb), self._stream()),
+                    "hoqp_wbc_build_tasks_batched")
+        return tasks, n_inst, m_inst, p_inst
+
+    def solve_wbc(self, dinp, out=None, entry="batched"):
+        """entry: "batched" (fused, one kernel) or "unfused" (three kernels, handle workspace)."""
+        B = dinp["M"].shape[0]
+        wi = self._wbc_inputs(dinp)
         if out is None:
             out = self.alloc_wbc_outputs(B)
         wo = WbcOutputs()
         for name, _ in WbcOutputs._fields_:
             if out.get(name) is not None:
                 setattr(wo, name, out[name].data_ptr())
-        self._check(self.lib.hoqp_solve_wbc_batched(self.h, C.byref(wi), C.byref(wo), self._stream()),
-                    "hoqp_solve_wbc_batched")
+        fn = {"batched": self.lib.hoqp_solve_wbc_batched, "unfused": self.lib.hoqp_solve_wbc_unfused}[entry]
+        self._check(fn(self.h, C.byref(wi), C.byref(wo), self._stream()), "hoqp_solve_wbc_" + entry)
         return out

@@ -1,6 +1,8 @@
 // shim_check.cpp -- drives include/hoqp.hpp the way the reference drives its own classes
 // (ConstructOptProblems, ho_qp_controller.cpp:120-141; CalcJointCmd, :7-25).  Used by
 // tests/test_gpu_shim.py: reads a text fixture, prints results as text.
+#include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -105,11 +107,56 @@ int main(int argc, char **argv)
 		std::printf("flags %d %d %d %d %d status %d\n", fl[0], fl[1], fl[2], fl[3], fl[4], ctl.GetStatus());
 		// the same cycle with the dynamics terms produced from (q, u) by the library
 		control::HoQpController ctl2;
-		ctl2.UseBuiltinDynamics();
+		ctl2.UseBuiltinDynamics(nullptr, 1);  // the fixture's h includes gravity
 		ctl2.SetBaseCmd(bc, bd, bdd);
 		ctl2.SetLegCmd(lc, ld, ldd, cp);
 		ctl2.CalcJointCmd(q, u);
 		print_vec("tau_builtin", ctl2.GetJointTorqueCmd());
+		// single-state drop-in latency: the reference's control loop calls CalcJointCmd once per
+		// 2.5 ms cycle (whole_body_controller.cpp:97-107, :609); argv[2] = repetitions
+		const int reps = argc > 2 ? std::atoi(argv[2]) : 0;
+		if (reps > 0) {
+			std::vector<double> us(reps), us2(reps), us3(reps);
+			for (int w = 0; w < 200; ++w)
+				ctl.CalcJointCmd(q, u);
+			for (int i = 0; i < reps; ++i) {
+				auto t0 = std::chrono::steady_clock::now();
+				ctl.CalcJointCmd(q, u);
+				us[i] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+			}
+			for (int i = 0; i < reps; ++i) {  // with the dynamics terms produced from (q, u) as well
+				auto t0 = std::chrono::steady_clock::now();
+				ctl2.CalcJointCmd(q, u);
+				us2[i] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+			}
+			// the reference's own call pattern on the task API: five HoQpProblem constructors, one GetSolution
+			hoqp_config cur = hoqp::default_config();
+			std::vector<TaskDefinition> tk(3);
+			tk[0].A = MatrixXd::Identity(6, 30);
+			tk[0].b = VectorXd::Zero(6);
+			tk[1].D = MatrixXd::Identity(8, 30);
+			tk[1].f = VectorXd::Zero(8);
+			tk[2].A = MatrixXd::Identity(30, 30);
+			tk[2].b = VectorXd::Zero(30);
+			(void)cur;
+			for (int i = 0; i < reps; ++i) {
+				auto t0 = std::chrono::steady_clock::now();
+				std::shared_ptr<control::HoQpProblem> pr(new control::HoQpProblem(tk[0]));
+				for (size_t k = 1; k < tk.size(); ++k)
+					pr = std::shared_ptr<control::HoQpProblem>(new control::HoQpProblem(tk[k], pr));
+				volatile double x0 = pr->GetSolution()(0);
+				(void)x0;
+				us3[i] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+			}
+			auto pct = [](std::vector<double> v, double p) {
+				std::sort(v.begin(), v.end());
+				return v[(size_t)(p * (v.size() - 1))];
+			};
+			std::printf("latency_us calcjointcmd median %.2f p99 %.2f max %.2f builtin_dynamics median %.2f p99 %.2f "
+				    "problem_chain median %.2f p99 %.2f reps %d\n",
+				    pct(us, 0.5), pct(us, 0.99), pct(us, 1.0), pct(us2, 0.5), pct(us2, 0.99), pct(us3, 0.5),
+				    pct(us3, 0.99), reps);
+		}
 	}
 	return 0;
 }

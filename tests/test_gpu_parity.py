@@ -470,6 +470,7 @@ def test_gait_sampler(solver_factory, oracle, kind, fix):
     dur = oracle.GAITS[kind][1]
     time = rng.uniform(0.0, 3.0 * dur, B)
     time[:40] = np.arange(40) * (dur / oracle.GAITS[kind][0])       # exactly on the step boundaries
+    time[40:60] = -rng.uniform(0.0, 2.0 * dur, 20)                  # negative times count as time 0
     vel = rng.normal(0.0, 0.2, (B, 2))
     stance = rng.normal(0.0, 0.3, (B, 4, 2))
     s = solver_factory("reference")
@@ -496,7 +497,7 @@ def test_standup_sampler_and_command_pipeline(solver_factory, oracle):
     rng = np.random.default_rng(32)
     B = 512
     s = solver_factory("reference")
-    t = rng.uniform(0.0, 4.0, B)
+    t = rng.uniform(-0.5, 4.0, B)
     pose = rng.normal(0.0, 0.1, (B, 3))
     bc, ct1 = s.standup_sample(torch.as_tensor(t).cuda(), 2.0, 0.5, torch.as_tensor(pose).cuda())
     s.synchronize()

@@ -309,6 +309,10 @@ def test_gait_sampler_known_answers(oracle):
     assert np.array_equal(ctc, CRAWL[:, (tc / 0.5).astype(int)].T) and ctc.sum(axis=1).min() == 2
     sw = ctc[:, 0] == 0
     assert np.all(lcc[sw, 2] > 0) and np.all(lcc[sw, 0] >= 0.3 - 1e-12) and np.all(lcc[sw, 0] <= 0.3 + 0.25 + 1e-12)
+    # a negative time counts as time 0 (never a negative gait step); t == duration wraps to 0
+    te = np.array([-0.75, 0.0, 10.0, -1e-9, -25.0])
+    le, ce = oracle.gait_sample("crawl", te, np.tile([0.1, 0.0], (5, 1)), np.tile(STANCE, (5, 1, 1)))
+    assert np.array_equal(ce, np.tile(CRAWL[:, 0], (5, 1))) and np.all(le == le[1])
 
 
 def test_standup_sampler_known_answers(oracle):
@@ -316,6 +320,9 @@ def test_standup_sampler_known_answers(oracle):
     assert np.allclose(bc[:, 0], 0.1) and np.allclose(bc[:, 1], -0.2) and np.allclose(bc[:, 2], [0.1, 0.3, 0.5, 0.5])
     assert np.allclose(bc[:, 5], [0.2, 0.2, 0.2, 0.0]) and np.all(bc[:, 3:5] == 0) and np.all(bc[:, 6:] == 0)
     assert np.all(ct == 1)
+    # before the ramp starts the position holds its first value (Drake's FirstOrderHold clamps)
+    bn, _ = oracle.standup_sample(np.array([-1.0]), 2.0, 0.5, np.array([[0.1, -0.2, 0.1]]))
+    assert np.allclose(bn[0, :3], [0.1, -0.2, 0.1]) and np.allclose(bn[0, 5], 0.2)
 
 
 def test_base_walk_plan_is_the_straight_line():
