@@ -67,7 +67,8 @@ typedef struct {
 void hoqp_default_config(hoqp_config *cfg);
 
 /* Replaces: HoQpController::HoQpController (ho_qp_controller.cpp:5).  One handle per host
- * thread and GPU; handles share no mutable state.  hoqp_solve_wbc_batched and hoqp_solve_tasks_batched keep no state in the
+ * thread and GPU; handles share no mutable state except the scratch array of
+ * hoqp_solve_wbc_noalloc.  hoqp_solve_wbc_batched and hoqp_solve_tasks_batched keep no state in the
  * handle and may be issued to any number of streams; the host-buffer entries and
  * hoqp_solve_wbc_unfused use handle-owned staging and must be issued one at a time per handle.
  * Every entry point makes the handle's device current for its own duration and restores the
@@ -161,6 +162,18 @@ int hoqp_solve_wbc_batched(hoqp_handle *h, const hoqp_wbc_inputs *in, const hoqp
  * cross-check of the fused kernel.  One stream at a time per handle (the workspace is shared).
  */
 int hoqp_solve_wbc_unfused(hoqp_handle *h, const hoqp_wbc_inputs *in, const hoqp_wbc_outputs *out, void *stream);
+
+/*
+ * No counterpart in the reference.  Allocation-free variant of hoqp_solve_wbc_unfused for callers
+ * that cannot allocate: code under HIP graph capture, tight control / serving loops, harnesses that
+ * forbid hipMalloc.  It calls no hipMalloc / hipFree / event creation; the task blocks go to a
+ * file-scope device array of HOQP_NOALLOC_MAX_BATCH * 21,868 bytes (5.6 MB) that every GPU the
+ * library runs on holds until the process ends.  batch > HOQP_NOALLOC_MAX_BATCH is rejected (-4).
+ * All calls on one GPU share that array: calls that overlap on one GPU (two streams, two handles on
+ * the same device) race; serialise them.  Results are those of hoqp_solve_wbc_unfused.
+ */
+#define HOQP_NOALLOC_MAX_BATCH 256
+int hoqp_solve_wbc_noalloc(hoqp_handle *h, const hoqp_wbc_inputs *in, const hoqp_wbc_outputs *out, void *stream);
 
 /*
  * Replaces: HoQpController::ConstructTasks (ho_qp_controller.cpp:147-184) alone -- the five

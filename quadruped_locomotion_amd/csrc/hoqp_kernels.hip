@@ -209,16 +209,26 @@ __global__ void __launch_bounds__(kWave) selftest_kernel(int *fail)
 // ===========================================================================
 using namespace hoqp;
 
+// ---------------------------------------------------------------------------
+// Scratch of the allocation-free entry (hoqp_solve_wbc_noalloc): the task blocks of up to
+// HOQP_NOALLOC_MAX_BATCH instances.  One copy per GPU, resident until the process ends; its device
+// address is taken once per device in hoqp_create (hipGetSymbolAddress) -- in host code the
+// array's NAME is only a stand-in, never a device address.
+// ---------------------------------------------------------------------------
 namespace {
 constexpr size_t kTaskDoubles = 180 + 6 + 1200 + 40 + 360 + 12 + 540 + 18 + 360 + 12;  // per instance
 constexpr size_t kTaskInts = 11;						       // n, m[5], p[5]
+constexpr size_t kScratchBytes = (size_t)HOQP_NOALLOC_MAX_BATCH * (kTaskDoubles * 8 + kTaskInts * 4);
 constexpr int kMaxDevices = 64;
 }  // namespace
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+static void *g_scratch_ptr[kMaxDevices];  // device address of `scratch` on each GPU (null: not taken yet)
 
 struct hoqp_handle {
 	hoqp_config cfg;
 	std::string err;
 	int max_lds = 0;
+	void *scratch_ptr = nullptr;  // this device's copy of `scratch`
 	// grow-only staging of the host-buffer entries: one device arena + one pinned host arena
 	char *stage_d = nullptr, *stage_h = nullptr;
 	size_t stage_cap = 0;
@@ -299,6 +309,16 @@ extern "C" int hoqp_create(const hoqp_config *cfg, hoqp_handle **out)
 	if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, cfg->device) != hipSuccess)
 		lds = 65536;
 	h->max_lds = lds;
+	// device address of the scratch array on THIS device (each GPU holds its own copy at its own address)
+	if (!g_scratch_ptr[cfg->device]) {
+		void *p = nullptr;
+		if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) {
+			delete h;
+			return -3;
+		}
+		g_scratch_ptr[cfg->device] = p;
+	}
+	h->scratch_ptr = g_scratch_ptr[cfg->device];
 	*out = h;
 	return 0;
 }
@@ -665,7 +685,8 @@ static int solve_wbc_unfused(hoqp_handle *h, const hoqp_wbc_inputs *in, const ho
 }
 
 // Same results as hoqp_solve_wbc_batched through the three-kernel path (task blocks materialised in
-// a handle-owned, grow-only workspace).  Kept as the cross-check of the fused kernel.
+// a handle-owned, grow-only workspace).  Kept as the cross-check of the fused kernel and as the
+// path the allocation-free entry shares its kernels with.
 extern "C" int hoqp_solve_wbc_unfused(hoqp_handle *h, const hoqp_wbc_inputs *in, const hoqp_wbc_outputs *out,
 				      void *stream)
 {
@@ -693,6 +714,32 @@ extern "C" int hoqp_solve_wbc_unfused(hoqp_handle *h, const hoqp_wbc_inputs *in,
 		h->ws_batch = B;
 	}
 	return solve_wbc_unfused(h, in, out, s, h->ws_d, h->ws_i, true);
+}
+
+// Allocation-free variant (no counterpart in the reference): for callers that cannot allocate --
+// HIP graph capture, tight control loops, harnesses that forbid hipMalloc.  The task blocks go to
+// the file-scope `scratch` array of this device; no hipMalloc / hipFree / event creation happens.
+extern "C" int hoqp_solve_wbc_noalloc(hoqp_handle *h, const hoqp_wbc_inputs *in, const hoqp_wbc_outputs *out,
+				      void *stream)
+{
+	if (!h)
+		return -1;
+	int rc = check_wbc_args(h, in, out);
+	if (rc)
+		return rc;
+	const int B = in->batch;
+	if (B > HOQP_NOALLOC_MAX_BATCH)
+		return fail(h, -4, "hoqp_solve_wbc_noalloc: batch exceeds HOQP_NOALLOC_MAX_BATCH");
+	if (B == 0)
+		return 0;
+	if (!h->scratch_ptr)
+		return fail(h, -3, "hoqp_solve_wbc_noalloc: scratch address not initialised");
+	ENTER_DEVICE(h);
+	// [doubles of B instances | ints of B instances]; every entry the solve reads is rewritten by
+	// wbc_build_kernel of this call, so nothing has to start at zero
+	double *ws_d = (double *)h->scratch_ptr;
+	int *ws_i = (int *)((char *)h->scratch_ptr + (size_t)HOQP_NOALLOC_MAX_BATCH * kTaskDoubles * 8);
+	return solve_wbc_unfused(h, in, out, (hipStream_t)stream, ws_d, ws_i, false);
 }
 
 // HoQpController::ConstructTasks (ho_qp_controller.cpp:147-184) as a batched dump: the five task

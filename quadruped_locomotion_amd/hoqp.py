@@ -30,11 +30,12 @@ STATUS_INFEASIBLE_START = 0x02
 STATUS_WORKSPACE = 0x04
 STATUS_NONFINITE = 0x08
 STATUS_BAD_EXTENT = 0x20
+NOALLOC_MAX_BATCH = 256
 
 EXPORTS = (
     "hoqp_default_config", "hoqp_create", "hoqp_destroy", "hoqp_last_error_string",
     "hoqp_solve_tasks_batched", "hoqp_solve_wbc_batched", "hoqp_solve_tasks_host", "hoqp_solve_wbc_host",
-    "hoqp_solve_wbc_unfused", "hoqp_wbc_build_tasks_batched",
+    "hoqp_solve_wbc_unfused", "hoqp_solve_wbc_noalloc", "hoqp_wbc_build_tasks_batched",
     "hoqp_default_quadruped_model", "hoqp_wbc_dynamics_batched", "hoqp_wbc_dynamics_host", "hoqp_wbc_poststep_batched",
     "hoqp_default_gait", "hoqp_gait_sample_batched", "hoqp_standup_sample_batched",
     "hoqp_base_walk_sample_batched", "hoqp_synchronize",
@@ -119,6 +120,7 @@ def load_library():
         lib.hoqp_solve_tasks_batched.argtypes = [C.c_void_p, C.POINTER(TaskBatch), C.POINTER(ResultBatch), C.c_void_p]
         lib.hoqp_solve_wbc_batched.argtypes = [C.c_void_p, C.POINTER(WbcInputs), C.POINTER(WbcOutputs), C.c_void_p]
         lib.hoqp_solve_wbc_unfused.argtypes = lib.hoqp_solve_wbc_batched.argtypes
+        lib.hoqp_solve_wbc_noalloc.argtypes = lib.hoqp_solve_wbc_batched.argtypes
         lib.hoqp_solve_wbc_host.argtypes = [C.c_void_p, C.POINTER(WbcInputs), C.POINTER(WbcOutputs)]
         lib.hoqp_solve_tasks_host.argtypes = [C.c_void_p, C.POINTER(TaskBatch), C.POINTER(ResultBatch)]
         lib.hoqp_wbc_build_tasks_batched.argtypes = [C.c_void_p, C.POINTER(WbcInputs), C.POINTER(TaskBatch), C.c_void_p]
@@ -432,7 +434,8 @@ class HoQpSolver:
         return tasks, n_inst, m_inst, p_inst
 
     def solve_wbc(self, dinp, out=None, entry="batched"):
-        """entry: "batched" (fused, one kernel) or "unfused" (three kernels, handle workspace)."""
+        """entry: "batched" (fused, one kernel), "unfused" (three kernels, handle workspace) or
+        "noalloc" (three kernels, static device scratch, batch <= NOALLOC_MAX_BATCH)."""
         B = dinp["M"].shape[0]
         wi = self._wbc_inputs(dinp)
         if out is None:
@@ -441,6 +444,7 @@ class HoQpSolver:
         for name, _ in WbcOutputs._fields_:
             if out.get(name) is not None:
                 setattr(wo, name, out[name].data_ptr())
-        fn = {"batched": self.lib.hoqp_solve_wbc_batched, "unfused": self.lib.hoqp_solve_wbc_unfused}[entry]
+        fn = {"batched": self.lib.hoqp_solve_wbc_batched, "unfused": self.lib.hoqp_solve_wbc_unfused,
+              "noalloc": self.lib.hoqp_solve_wbc_noalloc}[entry]
         self._check(fn(self.h, C.byref(wi), C.byref(wo), self._stream()), "hoqp_solve_wbc_" + entry)
         return out

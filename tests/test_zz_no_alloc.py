@@ -1,0 +1,46 @@
+"""GPU test of the allocation-free entry point (hoqp_solve_wbc_noalloc, include/hoqp.h): its outputs
+against hoqp_solve_wbc_unfused (the existing entry point whose kernels it shares; bit-exact, the
+arithmetic is identical) and against the oracle (1e-6, the north-star tolerance), on two calls in a
+row, the second with a smaller input; oversize batches are rejected."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from quadruped_locomotion_amd import anymal_model as am
+from quadruped_locomotion_amd import hoqp
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-6
+
+
+def _compare(s, oracle, inp):
+    d = s.to_device(inp)
+    got = {k: v.cpu().numpy() for k, v in s.solve_wbc(d, entry="noalloc").items()}
+    want = {k: v.cpu().numpy() for k, v in s.solve_wbc(d, entry="unfused").items()}
+    s.synchronize()
+    assert np.all(got["status"] == 0)
+    for key in want:
+        assert np.array_equal(got[key], want[key]), key          # same kernels, same arithmetic
+    ref, rc = oracle.wbc_solve_batch(inp, oracle.default_cfg("reference"), oracle.default_wbc_params("reference"),
+                                     threads=4)
+    assert rc == 0
+    for key in ("x", "qdd", "tau"):
+        err = np.abs(got[key] - ref[key]) / np.maximum(1.0, np.abs(ref[key]))
+        assert err.max() <= RTOL, (key, err.max())
+    err = np.abs(got["v"] - ref["v"][:, :40]) / np.maximum(1.0, np.abs(ref["v"][:, :40]))
+    assert err.max() <= RTOL
+
+
+def test_noalloc_entry_two_calls(solver_factory, oracle):
+    s = solver_factory("reference")
+    _compare(s, oracle, am.make_wbc_inputs(am.sample_states(hoqp.NOALLOC_MAX_BATCH, 41, "trot")))
+    _compare(s, oracle, am.make_wbc_inputs(am.sample_states(37, 42, "three")))     # smaller, other row counts
+
+
+def test_noalloc_entry_rejects_oversize(solver_factory):
+    s = solver_factory("reference")
+    d = s.to_device(am.make_wbc_inputs(am.sample_states(hoqp.NOALLOC_MAX_BATCH + 1, 43, "stance")))
+    with pytest.raises(RuntimeError, match="HOQP_NOALLOC_MAX_BATCH"):
+        s.solve_wbc(d, entry="noalloc")
