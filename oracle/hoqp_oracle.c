@@ -14,6 +14,12 @@
  * would pick an unpinned third-party solver), the kernel by complete-pivoting LU.
  * This restatement is cross-checked against numpy/scipy in tests/ only.
  *
+ * Two QP solvers (hoqp_oracle_cfg.solver): 1 (default) = the program in least-squares form with
+ * every factorization a Householder QR in long double -- the exact-arithmetic minimiser of the
+ * reference's program to ~1e-13, the value parity is asserted against; 0 = H = (AZ)'AZ + eps I
+ * formed and factored in double, which is what a double-precision restatement of
+ * ho_qp_problem.cpp:231-357 computes (kept as a second opinion and as the timed CPU baseline).
+ *
  * Every function names the reference file:line it follows (paths relative to the
  * reference root).  All matrices are dense row-major doubles.
  */
@@ -526,6 +532,368 @@ static int qp_solve(int N, const double *H, const double *c, int Mc, const doubl
 	return st;
 }
 
+/* ------------------------------------------------------------------------- */
+/* The same QP in LEAST-SQUARES form, extended precision (solver = 1)          */
+/* ------------------------------------------------------------------------- */
+/*
+ * The reference's H and c (ConstructHMatrix / ConstructCVector, ho_qp_problem.cpp:231-285) are
+ * H = B'B, c = -B'beta with  B = [A Z, 0 ; sqrt(eps) I, 0 ; 0, I],  beta = [b - A x ; 0 ; 0],
+ * so the QP of :291-300 is   min 1/2 |B xi - beta|^2   s.t.  C xi <= d.
+ * Forming H squares the condition number of A Z: with sigma_min(A Z) ~ 1e-3 (a leg near a singular
+ * posture) a double-precision Cholesky of H is good to ~1e-6 only, which is the tolerance of the
+ * whole parity claim.  This solver never forms H: every equality-constrained step is a
+ * minimum-norm least-squares solve by Householder QR with column pivoting in long double
+ * (64-bit mantissa), so its answer is the exact-arithmetic minimiser of the reference's program to
+ * ~1e-13 -- the authoritative value the HIP path is compared with.  The literal H form above stays
+ * as solver = 0 (what a double-precision restatement of the reference computes).
+ */
+typedef long double ldbl;
+
+static ldbl *lalloc(size_t n)
+{
+	ldbl *p = (ldbl *)calloc(n ? n : 1, sizeof(ldbl));
+	if (!p) {
+		fprintf(stderr, "hoqp_oracle: out of memory\n");
+		abort();
+	}
+	return p;
+}
+
+/* T (r x c) P = Q R, long double; as qr_colpiv */
+static int qr_colpiv_ld(int r, int c, ldbl *T, ldbl *Q, int *perm, ldbl rtol)
+{
+	for (int i = 0; i < r; ++i)
+		for (int j = 0; j < r; ++j)
+			Q[i * r + j] = (i == j) ? 1.0L : 0.0L;
+	for (int j = 0; j < c; ++j)
+		perm[j] = j;
+	int kmax = MIN(r, c), rank = 0;
+	ldbl first = 0.0L;
+	ldbl *v = lalloc(r);
+	for (int k = 0; k < kmax; ++k) {
+		int best = -1;
+		ldbl bn = -1.0L;
+		for (int j = k; j < c; ++j) {
+			ldbl s = 0.0L;
+			for (int i = k; i < r; ++i)
+				s += T[i * c + j] * T[i * c + j];
+			if (s > bn) {
+				bn = s;
+				best = j;
+			}
+		}
+		ldbl nrm = sqrtl(bn);
+		if (k == 0)
+			first = nrm;
+		if (!(nrm > rtol * first) || nrm == 0.0L)
+			break;
+		if (best != k) {
+			for (int i = 0; i < r; ++i) {
+				ldbl t = T[i * c + k];
+				T[i * c + k] = T[i * c + best];
+				T[i * c + best] = t;
+			}
+			int t = perm[k];
+			perm[k] = perm[best];
+			perm[best] = t;
+		}
+		ldbl alpha = T[k * c + k];
+		ldbl beta = (alpha >= 0.0L) ? -nrm : nrm;
+		ldbl vn2 = 0.0L;
+		for (int i = k; i < r; ++i) {
+			v[i] = T[i * c + k];
+			if (i == k)
+				v[i] = alpha - beta;
+			vn2 += v[i] * v[i];
+		}
+		if (vn2 > 0.0L) {
+			for (int j = k; j < c; ++j) {
+				ldbl s = 0.0L;
+				for (int i = k; i < r; ++i)
+					s += v[i] * T[i * c + j];
+				s *= 2.0L / vn2;
+				for (int i = k; i < r; ++i)
+					T[i * c + j] -= s * v[i];
+			}
+			for (int i = 0; i < r; ++i) {
+				ldbl s = 0.0L;
+				for (int t = k; t < r; ++t)
+					s += Q[i * r + t] * v[t];
+				s *= 2.0L / vn2;
+				for (int t = k; t < r; ++t)
+					Q[i * r + t] -= s * v[t];
+			}
+		}
+		T[k * c + k] = beta;
+		for (int i = k + 1; i < r; ++i)
+			T[i * c + k] = 0.0L;
+		++rank;
+	}
+	free(v);
+	return rank;
+}
+
+/* q = minimum-norm minimiser of |B q - beta| (B is r x c, any rank); complete orthogonal decomposition */
+static void lsq_minnorm_ld(int r, int c, const ldbl *B, const ldbl *beta, ldbl *q, ldbl rtol)
+{
+	for (int j = 0; j < c; ++j)
+		q[j] = 0.0L;
+	if (r == 0 || c == 0)
+		return;
+	ldbl *T = lalloc((size_t)r * c), *Q = lalloc((size_t)r * r), *c1 = lalloc(r), *y = lalloc(c);
+	int *perm = (int *)malloc(sizeof(int) * c);
+	memcpy(T, B, sizeof(ldbl) * r * c);
+	int k = qr_colpiv_ld(r, c, T, Q, perm, rtol);
+	for (int j = 0; j < k; ++j) {
+		ldbl s = 0.0L;
+		for (int i = 0; i < r; ++i)
+			s += Q[i * r + j] * beta[i];
+		c1[j] = s;
+	}
+	if (k == c) {
+		for (int i = k - 1; i >= 0; --i) {
+			ldbl s = c1[i];
+			for (int j = i + 1; j < k; ++j)
+				s -= T[i * c + j] * y[j];
+			y[i] = s / T[i * c + i];
+		}
+	} else if (k > 0) {
+		/* [R11 R12] y = c1, minimum norm:  (R')(c x k) P2 = Q2 R2  =>  y = Q2[:, :k] R2^-T P2' c1 */
+		ldbl *Tt = lalloc((size_t)c * k), *Q2 = lalloc((size_t)c * c), *w = lalloc(k);
+		int *p2 = (int *)malloc(sizeof(int) * k);
+		for (int i = 0; i < k; ++i)
+			for (int j = 0; j < c; ++j)
+				Tt[j * k + i] = T[i * c + j];
+		int k2 = qr_colpiv_ld(c, k, Tt, Q2, p2, 0.0L);
+		for (int i = 0; i < k2; ++i) { /* R2' w = P2' c1 (forward substitution) */
+			ldbl s = c1[p2[i]];
+			for (int j = 0; j < i; ++j)
+				s -= Tt[j * k + i] * w[j];
+			w[i] = s / Tt[i * k + i];
+		}
+		for (int j = 0; j < c; ++j) {
+			ldbl s = 0.0L;
+			for (int i = 0; i < k2; ++i)
+				s += Q2[j * c + i] * w[i];
+			y[j] = s;
+		}
+		free(Tt);
+		free(Q2);
+		free(w);
+		free(p2);
+	}
+	for (int j = 0; j < c; ++j)
+		q[perm[j]] = y[j];
+	free(T);
+	free(Q);
+	free(c1);
+	free(y);
+	free(perm);
+}
+
+/* primal active set on  min 1/2 |B xi - beta|^2  s.t.  C xi <= d  from a feasible xi (B: R x N) */
+static int lsq_primal_active_set(int N, int R, const ldbl *B, const ldbl *beta, int Mc, const ldbl *C, const ldbl *d,
+				 ldbl *xi, ldbl *lam, int maxit, int *iters_out)
+{
+	int status = QP_MAXIT;
+	int *W = (int *)malloc(sizeof(int) * (N + 1));
+	char *inW = (char *)calloc(Mc ? Mc : 1, 1);
+	int w = 0;
+	ldbl *g = lalloc(N), *p = lalloc(N), *T = lalloc((size_t)N * (N + 1)), *Q = lalloc((size_t)N * N);
+	ldbl *BZ = lalloc((size_t)R * N), *res = lalloc(R), *q = lalloc(N), *tmp = lalloc(N);
+	int *perm = (int *)malloc(sizeof(int) * (N + 1));
+	int it = 0, degenerate_run = 0;
+	for (int i = 0; i < Mc; ++i)
+		lam[i] = 0.0L;
+	for (it = 0; it < maxit; ++it) {
+		/* residual beta - B xi and gradient g = -B'(beta - B xi) */
+		for (int i = 0; i < R; ++i) {
+			ldbl s = beta[i];
+			for (int j = 0; j < N; ++j)
+				s -= B[i * N + j] * xi[j];
+			res[i] = s;
+		}
+		for (int j = 0; j < N; ++j) {
+			ldbl s = 0.0L;
+			for (int i = 0; i < R; ++i)
+				s -= B[i * N + j] * res[i];
+			g[j] = s;
+		}
+		int rw = 0;
+		if (w > 0) {
+			for (int i = 0; i < N; ++i)
+				for (int j = 0; j < w; ++j)
+					T[i * w + j] = C[W[j] * N + i];
+			rw = qr_colpiv_ld(N, w, T, Q, perm, 1e-15L);
+		} else {
+			for (int i = 0; i < N; ++i)
+				for (int j = 0; j < N; ++j)
+					Q[i * N + j] = (i == j) ? 1.0L : 0.0L;
+		}
+		int nf = N - rw;
+		for (int i = 0; i < N; ++i)
+			p[i] = 0.0L;
+		if (nf > 0) {
+			for (int i = 0; i < R; ++i)
+				for (int j = 0; j < nf; ++j) {
+					ldbl s = 0.0L;
+					for (int t = 0; t < N; ++t)
+						s += B[i * N + t] * Q[t * N + rw + j];
+					BZ[i * nf + j] = s;
+				}
+			lsq_minnorm_ld(R, nf, BZ, res, q, 1e-13L);
+			for (int i = 0; i < N; ++i) {
+				ldbl s = 0.0L;
+				for (int j = 0; j < nf; ++j)
+					s += Q[i * N + rw + j] * q[j];
+				p[i] = s;
+			}
+		}
+		ldbl pn = 0.0L, xn = 0.0L, gn = 0.0L;
+		for (int i = 0; i < N; ++i) {
+			pn = MAX(pn, fabsl(p[i]));
+			xn = MAX(xn, fabsl(xi[i]));
+			gn = MAX(gn, fabsl(g[i]));
+		}
+		if (pn <= 1e-13L * (1.0L + xn)) {
+			if (w == 0) {
+				status = QP_OK;
+				break;
+			}
+			for (int j = 0; j < rw; ++j) {
+				ldbl s = 0.0L;
+				for (int t = 0; t < N; ++t)
+					s += Q[t * N + j] * g[t];
+				tmp[j] = -s;
+			}
+			for (int j = rw - 1; j >= 0; --j) {
+				ldbl s = tmp[j];
+				for (int t = j + 1; t < rw; ++t)
+					s -= T[j * w + t] * q[t];
+				q[j] = s / T[j * w + j];
+			}
+			int drop = -1;
+			ldbl worst = -1e-9L * (1.0L + gn);
+			for (int j = 0; j < rw; ++j) {
+				int wi = perm[j];
+				if (degenerate_run > 2 * N) { /* Bland: lowest index */
+					if (q[j] < -1e-9L * (1.0L + gn) && (drop < 0 || W[wi] < W[drop]))
+						drop = wi;
+				} else if (q[j] < worst) {
+					worst = q[j];
+					drop = wi;
+				}
+			}
+			if (drop < 0) {
+				for (int j = 0; j < rw; ++j)
+					lam[W[perm[j]]] = q[j];
+				status = QP_OK;
+				break;
+			}
+			inW[W[drop]] = 0;
+			for (int j = drop; j < w - 1; ++j)
+				W[j] = W[j + 1];
+			--w;
+			continue;
+		}
+		ldbl alpha = 1.0L;
+		int block = -1;
+		for (int i = 0; i < Mc; ++i) {
+			if (inW[i])
+				continue;
+			ldbl cp = 0.0L, cx = 0.0L, cn = 0.0L;
+			for (int j = 0; j < N; ++j) {
+				cp += C[i * N + j] * p[j];
+				cx += C[i * N + j] * xi[j];
+				cn = MAX(cn, fabsl(C[i * N + j]));
+			}
+			if (cp > 1e-14L * cn * pn) {
+				ldbl a = (d[i] - cx) / cp;
+				if (a < 0.0L)
+					a = 0.0L;
+				if (a < alpha || (a == alpha && block >= 0 && degenerate_run > 2 * N && i < block)) {
+					alpha = a;
+					block = i;
+				}
+			}
+		}
+		for (int i = 0; i < N; ++i)
+			xi[i] += alpha * p[i];
+		degenerate_run = (alpha <= 1e-16L) ? degenerate_run + 1 : 0;
+		if (block >= 0) {
+			W[w++] = block;
+			inW[block] = 1;
+		}
+	}
+	if (iters_out)
+		*iters_out = it;
+	free(W);
+	free(inW);
+	free(g);
+	free(p);
+	free(T);
+	free(Q);
+	free(BZ);
+	free(res);
+	free(q);
+	free(tmp);
+	free(perm);
+	return status;
+}
+
+/* phase 1 (only if xi violates C xi <= d): min 1/2 |s|^2 s.t. C xi - s <= d, then phase 2 */
+static int lsq_qp_solve(int N, int R, const ldbl *B, const ldbl *beta, int Mc, const ldbl *C, const ldbl *d, ldbl *xi,
+			ldbl *lam, int maxit, int *iters_out)
+{
+	ldbl viol = 0.0L, scale = 1.0L;
+	for (int i = 0; i < Mc; ++i) {
+		ldbl s = -d[i];
+		for (int j = 0; j < N; ++j)
+			s += C[i * N + j] * xi[j];
+		viol = MAX(viol, s);
+		scale = MAX(scale, fabsl(d[i]));
+	}
+	int it1 = 0, st = QP_OK;
+	if (viol > 1e-9L * scale) {
+		int N1 = N + Mc;
+		ldbl *B1 = lalloc((size_t)Mc * N1), *b1 = lalloc(Mc), *C1 = lalloc((size_t)Mc * N1);
+		ldbl *x1 = lalloc(N1), *l1 = lalloc(Mc);
+		for (int i = 0; i < Mc; ++i) {
+			B1[i * N1 + N + i] = 1.0L;
+			for (int j = 0; j < N; ++j)
+				C1[i * N1 + j] = C[i * N + j];
+			C1[i * N1 + N + i] = -1.0L;
+		}
+		memcpy(x1, xi, sizeof(ldbl) * N);
+		for (int i = 0; i < Mc; ++i) {
+			ldbl s = -d[i];
+			for (int j = 0; j < N; ++j)
+				s += C[i * N + j] * xi[j];
+			x1[N + i] = MAX(0.0L, s);
+		}
+		st = lsq_primal_active_set(N1, Mc, B1, b1, Mc, C1, d, x1, l1, maxit, &it1);
+		memcpy(xi, x1, sizeof(ldbl) * N);
+		ldbl smax = 0.0L;
+		for (int i = 0; i < Mc; ++i)
+			smax = MAX(smax, fabsl(x1[N + i]));
+		free(B1);
+		free(b1);
+		free(C1);
+		free(x1);
+		free(l1);
+		if (smax > 1e-9L * scale) {
+			if (iters_out)
+				*iters_out = it1;
+			return st | QP_INFEASIBLE;
+		}
+	}
+	int it2 = 0;
+	st |= lsq_primal_active_set(N, R, B, beta, Mc, C, d, xi, lam, maxit, &it2);
+	if (iters_out)
+		*iters_out = it1 + it2;
+	return st;
+}
+
 /* exported for unit tests of the QP stand-in */
 int hoqp_oracle_qp(int N, const double *H, const double *c, int Mc, const double *C, const double *d,
 		   double *xi, double *lam, int maxit, int *iters)
@@ -554,10 +922,12 @@ int hoqp_oracle_fullpivlu_kernel(int r, int c, const double *A, double *Kout, in
 	int size = MIN(r, c), nonzero = size;
 	double maxpivot = 0.0;
 	for (int k = 0; k < size; ++k) {
+		/* biggest |coefficient| of the bottom-right corner; among equal ones the first in column-major
+		 * order, as Eigen's maxCoeff visitor walks a column-major matrix (strict '>' keeps the first) */
 		int bi = k, bj = k;
 		double best = 0.0;
-		for (int i = k; i < r; ++i)
-			for (int j = k; j < c; ++j)
+		for (int j = k; j < c; ++j)
+			for (int i = k; i < r; ++i)
 				if (fabs(lu[i * c + j]) > best) {
 					best = fabs(lu[i * c + j]);
 					bi = i;
@@ -659,6 +1029,7 @@ void hoqp_oracle_default_cfg(hoqp_oracle_cfg *cfg)
 	cfg->zero_kernel_col = 1; /* Q6, Eigen kernel() of a full-column-rank matrix */
 	cfg->nullspace_basis = 0; /* FullPivLU, math.hpp:99-104 */
 	cfg->max_iter = 2000;
+	cfg->solver = 1; /* authoritative: least-squares form in long double; 0 = the literal H + eps I form in double */
 }
 
 /*
@@ -764,10 +1135,48 @@ int hoqp_oracle_solve_tasks(const hoqp_oracle_cfg *cfg, int n, int K, const int 
 			}
 		}
 		/* SolveQp, :337-357 */
-		if (N > 0)
-			/* pivots <= 100*eps_ are indistinguishable from the eps_*I term: the solve is
+		if (N > 0 && cfg->solver == 0) {
+			/* literal form.  Pivots <= 100*eps_ are indistinguishable from the eps_*I term: the solve is
 			 * the eps_ -> 0 (minimum-norm) limit of the reference's regularised QP */
 			st = qp_solve(N, H, c, Mc, Dh, fh, xi, lam, cfg->max_iter, &it, 100.0 * cfg->eps);
+		} else if (N > 0) {
+			/* least-squares form (see lsq_primal_active_set): B = [A Z, 0 ; sqrt(eps) I, 0 ; 0, I] */
+			const int has_reg = has_eq && nz > 0 && cfg->eps > 0.0;
+			const int mrows = (has_eq && nz > 0) ? mk : 0;
+			const int R = mrows + (has_reg ? nz : 0) + nv;
+			ldbl *B = lalloc((size_t)R * N), *beta = lalloc(R), *Cl = lalloc((size_t)Mc * N), *dl = lalloc(Mc);
+			ldbl *xl = lalloc(N), *ll = lalloc(Mc);
+			for (int i = 0; i < mrows; ++i) {
+				for (int j = 0; j < nz; ++j)
+					B[i * N + j] = AZ[i * nz + j];
+				ldbl r = bk[i];
+				for (int t = 0; t < n; ++t)
+					r -= (ldbl)Ak[i * n + t] * (ldbl)x[t];
+				beta[i] = r;
+			}
+			if (has_reg) {
+				const ldbl se = sqrtl((ldbl)cfg->eps);
+				for (int j = 0; j < nz; ++j)
+					B[(mrows + j) * N + j] = se;
+			}
+			for (int i = 0; i < nv; ++i)
+				B[(R - nv + i) * N + nz + i] = 1.0L;
+			for (int i = 0; i < Mc * N; ++i)
+				Cl[i] = Dh[i];
+			for (int i = 0; i < Mc; ++i)
+				dl[i] = fh[i];
+			for (int i = 0; i < N; ++i)
+				xl[i] = xi[i];
+			st = lsq_qp_solve(N, R, B, beta, Mc, Cl, dl, xl, ll, cfg->max_iter, &it);
+			for (int i = 0; i < N; ++i)
+				xi[i] = (double)xl[i];
+			free(B);
+			free(beta);
+			free(Cl);
+			free(dl);
+			free(xl);
+			free(ll);
+		}
 		memcpy(z, xi, sizeof(double) * nz);
 		memcpy(v, xi + nz, sizeof(double) * nv);
 		/* GetSolution, :46-51 */

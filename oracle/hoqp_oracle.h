@@ -7,13 +7,6 @@
 
 #ifdef __cplusplus
 extern "C" {
-/* N3: command / gait sampler (leg_planner.cpp, base_planner.cpp:272-317) */
-void hoqp_oracle_gait_sample(int N, int n_steps, double duration, const int *schedule, double apex,
-			     int fix_derivatives, const double *time, const double *vel_cmd, const double *stance0,
-			     double *leg_cmd, int *contact);
-void hoqp_oracle_standup_sample(int N, double seconds, double target_height, const double *time,
-				const double *curr_pose, double *base_cmd, int *contact);
-
 #endif
 
 typedef struct {
@@ -23,6 +16,7 @@ typedef struct {
 	int zero_kernel_col;	/* Q6: 1 = Eigen kernel() returns one zero column */
 	int nullspace_basis;	/* 0 = FullPivLU kernel (math.hpp:99-104), 1 = Householder */
 	int max_iter;
+	int solver;		/* 1 = least-squares form in long double (authoritative); 0 = literal H + eps I, double */
 } hoqp_oracle_cfg;
 
 typedef struct {
@@ -82,16 +76,6 @@ int hoqp_oracle_wbc_solve(const hoqp_oracle_cfg *cfg, const hoqp_oracle_wbc_para
 int hoqp_oracle_wbc_solve_batch(const hoqp_oracle_cfg *cfg, const hoqp_oracle_wbc_params *prm, int N,
 				const hoqp_oracle_wbc_state *s, hoqp_oracle_wbc_result *out, int threads);
 
-#ifdef __cplusplus
-}
-/* N3: command / gait sampler (leg_planner.cpp, base_planner.cpp:272-317) */
-void hoqp_oracle_gait_sample(int N, int n_steps, double duration, const int *schedule, double apex,
-			     int fix_derivatives, const double *time, const double *vel_cmd, const double *stance0,
-			     double *leg_cmd, int *contact);
-void hoqp_oracle_standup_sample(int N, double seconds, double target_height, const double *time,
-				const double *curr_pose, double *base_cmd, int *contact);
-
-#endif
 /* Post-solve step: Integrator::Integrate twice (integrator.cpp:31-36, called by
  * WholeBodyController::SetJointCmdFromIntegrators, whole_body_controller.cpp:148-155) and
  * JointController::CalcJointTorques (joint_controller.cpp:103-110); arrays [N][12]; q_cmd and
@@ -106,4 +90,7 @@ void hoqp_oracle_gait_sample(int N, int n_steps, double duration, const int *sch
 void hoqp_oracle_standup_sample(int N, double seconds, double target_height, const double *time,
 				const double *curr_pose, double *base_cmd, int *contact);
 
+#ifdef __cplusplus
+}
+#endif
 #endif

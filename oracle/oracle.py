@@ -23,7 +23,8 @@ def build(force: bool = False) -> str:
 
 class Cfg(C.Structure):
     _fields_ = [("eps", C.c_double), ("gate_prior_ineq", C.c_int), ("slack_order_quirk", C.c_int),
-                ("zero_kernel_col", C.c_int), ("nullspace_basis", C.c_int), ("max_iter", C.c_int)]
+                ("zero_kernel_col", C.c_int), ("nullspace_basis", C.c_int), ("max_iter", C.c_int),
+                ("solver", C.c_int)]
 
 
 class WbcParams(C.Structure):
@@ -78,17 +79,22 @@ def _ip(a):
     return a.ctypes.data_as(C.POINTER(C.c_int))
 
 
-def default_cfg(mode: str = "reference", nullspace: str | None = None) -> Cfg:
+def default_cfg(mode: str = "reference", nullspace: str | None = None, solver: str = "lsq") -> Cfg:
+    """solver "lsq": every QP in least-squares form, Householder QR in long double (authoritative);
+    "literal": H = (AZ)'AZ + eps I formed and factored in double, as a double-precision restatement of
+    ho_qp_problem.cpp:231-357 computes it (used as the CPU baseline and as a second opinion)."""
     cfg = Cfg()
     lib().hoqp_oracle_default_cfg(C.byref(cfg))
+    cfg.solver = {"lsq": 1, "literal": 0}[solver]
     if mode == "paper":
         cfg.gate_prior_ineq = 0
         cfg.slack_order_quirk = 0
         cfg.zero_kernel_col = 0
         cfg.nullspace_basis = 1
-        # "paper" = the algorithm without the reference's eps_*I regulariser; the oracle needs a
-        # tiny positive value for its pivot floor (100*eps), 1e-15 is below fp64 resolution here.
-        cfg.eps = 1e-15
+        # "paper" = the algorithm without the reference's eps_*I regulariser: minimum-norm least squares
+        # (the literal solver needs a tiny positive value for its pivot floor 100*eps; 1e-15 is below
+        # fp64 resolution here)
+        cfg.eps = 0.0 if cfg.solver == 1 else 1e-15
     elif mode != "reference":
         raise ValueError(mode)
     if nullspace == "householder":
