@@ -724,7 +724,9 @@ static int lsq_primal_active_set(int N, int R, const ldbl *B, const ldbl *beta, 
 			for (int i = 0; i < N; ++i)
 				for (int j = 0; j < w; ++j)
 					T[i * w + j] = C[W[j] * N + i];
-			rw = qr_colpiv_ld(N, w, T, Q, perm, 1e-15L);
+			/* rank tolerances follow the precision of the DATA (C and B hold products rounded to
+			 * double: dependent rows are dependent to ~1e-16 only), not of the arithmetic */
+			rw = qr_colpiv_ld(N, w, T, Q, perm, 1e-12L);
 		} else {
 			for (int i = 0; i < N; ++i)
 				for (int j = 0; j < N; ++j)
@@ -741,7 +743,7 @@ static int lsq_primal_active_set(int N, int R, const ldbl *B, const ldbl *beta, 
 						s += B[i * N + t] * Q[t * N + rw + j];
 					BZ[i * nf + j] = s;
 				}
-			lsq_minnorm_ld(R, nf, BZ, res, q, 1e-13L);
+			lsq_minnorm_ld(R, nf, BZ, res, q, 1e-12L);
 			for (int i = 0; i < N; ++i) {
 				ldbl s = 0.0L;
 				for (int j = 0; j < nf; ++j)

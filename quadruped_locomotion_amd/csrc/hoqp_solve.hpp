@@ -26,6 +26,9 @@ constexpr int SROW = 36;  // row stride of the task staging buffer of the n_z ==
 			  // aligned rows); the matrix-core projection loads its operand from global memory
 constexpr int XROWS = 16; // dumped unpivoted columns (rank-deficient least squares); aliases S
 constexpr int CHUNK = 16; // task rows per projection pass (one 16 x K matrix-core operand tile)
+constexpr int kReplaySteps = 2;	  // inequality-only levels whose x step the reference replay can carry
+// the reference replay runs when eps / (smallest pivot)^2 of an unconstrained level exceeds this
+constexpr double kReplayTau = 3e-8;
 
 static_assert(NR >= HOQP_MAX_VARS, "register tiles must cover n");
 static_assert(16 * NSR >= HOQP_MAX_VARS + HOQP_MAX_INEQ_ROWS, "row slots must cover Z and G");
@@ -54,7 +57,7 @@ struct SolveArgs {
 
 // byte offsets of the LDS arrays (shared by host sizing and device addressing)
 struct LdsOff {
-	int Z, x, G, g, vs, s, c, TV, S, BL, r0, rho, a0, tau, rdiag, rhs, X, tmp, dump, b3, pivlane, W, xlane, colpos, vlist, total;
+	int Z, x, G, g, vs, s, c, TV, S, BL, r0, rho, a0, tau, rdiag, rhs, X, tmp, dump, b3, xstep, pivlane, W, xlane, colpos, vlist, total;
 };
 
 __host__ __device__ inline LdsOff lds_offsets(const SolveArgs &a)
@@ -88,6 +91,7 @@ __host__ __device__ inline LdsOff lds_offsets(const SolveArgs &a)
 	o.tmp = take(8 * kWave);
 	o.dump = take(8 * kWave);  // per-lane sink of predicated-off stores
 	o.b3 = take(8 * 24);	   // fused WBC entry: right-hand side of the tracking level
+	o.xstep = take(8 * NR * kReplaySteps);  // x steps of inequality-only levels (reference replay)
 	o.pivlane = take(4 * NR);
 	o.W = take(4 * NR);
 	o.xlane = take(4 * XROWS);
@@ -99,7 +103,7 @@ __host__ __device__ inline LdsOff lds_offsets(const SolveArgs &a)
 
 #ifdef __HIP_DEVICE_COMPILE__
 struct Lds {
-	ldsd *Z, *x, *G, *g, *vs, *s, *c, *TV, *S, *BL, *r0, *rho, *a0, *tau, *rdiag, *rhs, *X, *tmp, *dump, *b3;
+	ldsd *Z, *x, *G, *g, *vs, *s, *c, *TV, *S, *BL, *r0, *rho, *a0, *tau, *rdiag, *rhs, *X, *tmp, *dump, *b3, *xstep;
 	ldsi *pivlane, *W, *xlane, *colpos, *vlist;
 };
 
@@ -127,6 +131,7 @@ __device__ __forceinline__ Lds lds_bind(const SolveArgs &a, HOQP_LDS char *base)
 	l.tmp = (ldsd *)(base + o.tmp);
 	l.dump = (ldsd *)(base + o.dump);
 	l.b3 = (ldsd *)(base + o.b3);
+	l.xstep = (ldsd *)(base + o.xstep);
 	l.pivlane = (ldsi *)(base + o.pivlane);
 	l.W = (ldsi *)(base + o.W);
 	l.xlane = (ldsi *)(base + o.xlane);
@@ -605,7 +610,7 @@ __device__ __forceinline__ double gauss_jordan8(double mval, double gval)
 // l.X[u*ld + i] with their lanes listed in l.xlane[0..nunp).
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ double ls_solve_reg(int k1, int k2, int qB0, int qB1, int nunp, double eps, int ld,
-				      double *res_norm2, const Lds &l)
+				      double *res_norm2, const Lds &l, double *dmin_out = nullptr)
 {
 	const int lane = lane_id();
 	const int rb = k2 - k1;
@@ -632,6 +637,8 @@ __device__ __forceinline__ double ls_solve_reg(int k1, int k2, int qB0, int qB1,
 		// the estimate of sigma_min the two extra triangular solves are skipped while that is
 		// below 1e-10 (tolerance of the whole path: 1e-6).
 		const double dmin = wave_min(act ? fabs(rdg) : 1e300);
+		if (dmin_out)
+			*dmin_out = dmin;
 		if (eps != 0.0 && eps > 1e-10 * dmin * dmin) {
 			double Urow[NR];
 			load_Urow(Urow, k1, rb, l);
@@ -948,7 +955,11 @@ __device__ __forceinline__ void project_task(const double *__restrict__ rows_g, 
 // ---------------------------------------------------------------------------
 typedef double d4v __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void load_bm(double (&bm)[NR / 4][2], int n, int nz, int ld, const Lds &l)
+// B operand [Zm | xv] from any LDS matrix Zm (n x nz, leading dimension ldz) and vector xv; `ident`:
+// Zm is not read and stands for the identity.  (An explicit flag, never a null test: the solver's Z
+// sits at LDS offset 0, and offset 0 is what a null test of an LDS pointer compares with.)
+__device__ __forceinline__ void load_bm_from(double (&bm)[NR / 4][2], int n, int nz, int ldz, const ldsd *Zm, const ldsd *xv,
+					     bool ident)
 {
 	const int lane = lane_id(), j16 = lane & 15, q4 = lane >> 4;
 #pragma unroll
@@ -958,7 +969,7 @@ __device__ __forceinline__ void load_bm(double (&bm)[NR / 4][2], int n, int nz, 
 #pragma unroll
 		for (int cb = 0; cb < 2; ++cb) {
 			const int j = 16 * cb + j16;
-			const ldsd *src = (j < nz) ? l.Z + kc * ld + j : l.x + kc;
+			const ldsd *src = (j < nz && !ident) ? Zm + kc * ldz + j : xv + kc;
 			bm[kb][cb] = *src;
 		}
 	}
@@ -973,10 +984,25 @@ __device__ __forceinline__ void load_bm(double (&bm)[NR / 4][2], int n, int nz, 
 #pragma unroll
 		for (int cb = 0; cb < 2; ++cb) {
 			const int j = 16 * cb + j16;
-			bm[kb][cb] = sel(k < n && j <= nz, bm[kb][cb]);
+			double v = sel(k < n && j <= nz, bm[kb][cb]);
+			if (ident && j < nz)
+				v = (k == j && k < n) ? 1.0 : 0.0;
+			bm[kb][cb] = v;
 		}
 	}
 }
+
+__device__ __forceinline__ void load_bm(double (&bm)[NR / 4][2], int n, int nz, int ld, const Lds &l)
+{
+	load_bm_from(bm, n, nz, ld, l.Z, l.x, false);
+}
+
+// destination of a projection: rows of (A Z) to M[row * ldm + j], right-hand sides to rhs[row]
+struct ProjDst {
+	ldsd *M;
+	int ldm;
+	ldsd *rhs;
+};
 
 // Where the matrix-core operand of a task chunk comes from.  fetch() issues the loads of one
 // chunk of 16 rows (the next chunk's loads are in flight during the multiply), take() waits for
@@ -1084,8 +1110,8 @@ struct WbcLevelSrc {
 };
 
 template <typename Src>
-__device__ __forceinline__ void project_task_mfma(Src &src, int rows, int nz, int ld, const double (&bm)[NR / 4][2],
-						  bool to_T, int P, const Lds &l)
+__device__ __forceinline__ void project_task_mfma(Src &src, int rows, int nz, const double (&bm)[NR / 4][2],
+						  const ProjDst dstm, const Lds &l)
 {
 	const int lane = lane_id();
 	const int j16 = lane & 15, q4 = lane >> 4;
@@ -1123,13 +1149,8 @@ __device__ __forceinline__ void project_task_mfma(Src &src, int rows, int nz, in
 				const bool rok = i < nr;
 				const double v = cb ? acc1[r] : acc0[r];
 				ldsd *dst = l.dump + lane;
-				if (to_T) {
-					dst = (isZ && rok) ? l.TV + (r0 + i) * ld + j : dst;
-					dst = (isX && rok) ? l.rhs + (r0 + i) : dst;
-				} else {
-					dst = (isZ && rok) ? l.G + (P + r0 + i) * ld + j : dst;
-					dst = (isX && rok) ? l.g + (P + r0 + i) : dst;
-				}
+				dst = (isZ && rok) ? dstm.M + (r0 + i) * dstm.ldm + j : dst;
+				dst = (isX && rok) ? dstm.rhs + (r0 + i) : dst;
 				*dst = isX ? rvr[r] - v : v;
 			}
 		}
@@ -1162,6 +1183,8 @@ struct LevelState {
 	int P;	   // live stored inequality rows
 	int Pout;  // inequality rows emitted so far (offset of this level's slacks in out.v)
 	int status;
+	int replay_ok;	// every level so far can be replayed literally (see ref_replay)
+	int nskip;	// inequality-only levels whose x step is stored in l.xstep
 	unsigned long long t_last;
 };
 
@@ -1352,6 +1375,325 @@ __device__ __forceinline__ void level_update_t(const Lds &l, int n, int Pg, int 
 }
 
 // ---------------------------------------------------------------------------
+// Reference replay.  The reference regularises every level in the coordinates of ITS null-space
+// basis -- min |A Z z - r|^2 + eps |z|^2 with Z the FullPivLU kernel chain (ho_qp_problem.cpp:
+// 172-178, 244-246, math.hpp:99-104) -- and |z| in those coordinates is the norm of a SUBSET of
+// the entries of the step x_k - x_{k-1} (the LU's free columns), not its Euclidean norm.  The fast
+// path keeps orthonormal bases and reproduces the eps bias to first order in the Euclidean
+// metric; the difference is ~ (eps / sigma_min^2) * O(1..10) relative, invisible (<= 1e-7) on a
+// well-conditioned level and above the 1e-6 parity tolerance once sigma_min(A Z) < ~3e-3 (a leg
+// near a singular posture at the tracking level of the WBC).  When an unconstrained level's
+// smallest pivot says so (eps > kReplayTau * dmin^2), the levels 0..k are recomputed literally as
+// the reference does them -- complete-pivoting LU kernels in Eigen's pivot order, regularised
+// least squares by Householder QR of the stacked system (never forming H) -- and x_k is replaced
+// by the result; the orthonormal chain goes on unchanged (the two bases span the same space).
+// Slow and simple on purpose (one LDS access at a time): it runs for ~0.01 % of stance states and
+// ~10 % of three-contact states.  It needs the inequality workspace G, the reflector store and the
+// staging buffer as scratch, so it only runs when no later level looks at stored rows; levels that
+// solved a QP with equality rows cannot be replayed (the fast path's answer stands).
+// ---------------------------------------------------------------------------
+// Complete-pivoting LU of M (r x c, stride c) in place, Eigen's FullPivLU: the pivot is the largest
+// |coefficient| of the remaining corner, among equal ones the first in column-major order.  Returns
+// the rank (pivots above maxpivot * eps_mach * min(r, c)); cperm[j] = original column at position j.
+__device__ __forceinline__ int lds_fullpivlu(ldsd *M, int r, int c, ldsi *cperm)
+{
+	const int lane = lane_id();
+	if (lane < c)
+		cperm[lane] = lane;
+	wave_sync();
+	const int size = min(r, c);
+	double maxpivot = 0.0;
+	int nonzero = size;
+	for (int k = 0; k < size; ++k) {
+		double best = -1.0;
+		int bi = k;
+		if (lane >= k && lane < c)
+			for (int i = k; i < r; ++i) {
+				const double v = fabs(M[i * c + lane]);
+				if (v > best) {
+					best = v;
+					bi = i;
+				}
+			}
+		const double mx = wave_max(best);
+		if (!(mx > 0.0)) {
+			nonzero = k;
+			break;
+		}
+		const unsigned long long bal = __ballot(best == mx);
+		const int bj = uni(__ffsll((long long)bal) - 1);
+		bi = uni(__builtin_amdgcn_readlane(bi, bj));
+		maxpivot = fmax(maxpivot, mx);
+		wave_sync();
+		if (bi != k && lane < c) {
+			const double t0 = M[k * c + lane], t1 = M[bi * c + lane];
+			M[k * c + lane] = t1;
+			M[bi * c + lane] = t0;
+		}
+		wave_sync();
+		if (bj != k) {
+			if (lane < r) {
+				const double t0 = M[lane * c + k], t1 = M[lane * c + bj];
+				M[lane * c + k] = t1;
+				M[lane * c + bj] = t0;
+			}
+			if (lane == 0) {
+				const int t0 = cperm[k], t1 = cperm[bj];
+				cperm[k] = t1;
+				cperm[bj] = t0;
+			}
+		}
+		wave_sync();
+		const double piv = M[k * c + k];
+		if (lane > k && lane < r)
+			M[lane * c + k] = M[lane * c + k] / piv;
+		wave_sync();
+		if (lane > k && lane < c)
+			for (int i = k + 1; i < r; ++i)
+				M[i * c + lane] = fma(-M[i * c + k], M[k * c + lane], M[i * c + lane]);
+		wave_sync();
+	}
+	const double thr = maxpivot * (kEpsMach * (double)size);
+	const bool sig = lane < nonzero && fabs(M[(lane < nonzero ? lane : 0) * c + (lane < nonzero ? lane : 0)]) > thr;
+	return __popcll(__ballot(sig));
+}
+
+// K (c x dk, stride dk, dk = c - rank) = FullPivLU::kernel() from the factors above:
+// rows of the pivot columns = -U11^-1 U12, rows of the free columns = identity.
+__device__ __forceinline__ void lds_lu_kernel(const ldsd *M, int c, int rank, const ldsi *cperm, ldsd *K)
+{
+	const int lane = lane_id();
+	const int dk = c - rank;
+	if (lane < dk) {
+		for (int q = 0; q < dk; ++q)
+			K[cperm[rank + q] * dk + lane] = (q == lane) ? 1.0 : 0.0;
+		for (int i = rank - 1; i >= 0; --i) {
+			double s = M[i * c + rank + lane];
+			for (int j = i + 1; j < rank; ++j)
+				s = fma(M[i * c + j], K[cperm[j] * dk + lane], s);  // K holds -X
+			K[cperm[i] * dk + lane] = -(s / M[i * c + i]);
+		}
+	}
+	wave_sync();
+}
+
+// zout (nz) = argmin |M z - r|^2 + eps |z|^2, M (m x nz, stride nz) and r in LDS, by Householder QR
+// of the stacked system, one row per lane: m > nz:  [M; sqrt(eps) I] z = [r; 0];  m <= nz (dual):
+// z = M' w with [M'; sqrt(eps) I] w = [0; r / sqrt(eps)].  W: (m + nz) x (min(m, nz) + 1) doubles.
+__device__ __forceinline__ void lds_reg_solve(const ldsd *M, const ldsd *r, int m, int nz, double eps, ldsd *W, ldsd *wv,
+					      ldsd *zout)
+{
+	const int lane = lane_id();
+	const bool dual = m <= nz;
+	const int C = dual ? m : nz, R = m + nz, ldw = C + 1;
+	const double se = sqrt(eps);
+	if (lane < R)
+		for (int j = 0; j <= C; ++j) {
+			double v;
+			if (dual) {
+				if (lane < nz)
+					v = (j < C) ? M[j * nz + lane] : 0.0;
+				else
+					v = (j < C) ? ((lane - nz == j) ? se : 0.0) : r[lane - nz] / se;
+			} else {
+				if (lane < m)
+					v = (j < C) ? M[lane * nz + j] : r[lane];
+				else
+					v = (j < C) ? ((lane - m == j) ? se : 0.0) : 0.0;
+			}
+			W[lane * ldw + j] = v;
+		}
+	wave_sync();
+	for (int k = 0; k < C; ++k) {
+		const bool on = lane >= k && lane < R;
+		double v = on ? W[(on ? lane : 0) * ldw + k] : 0.0;
+		const double alpha = readlane_d(v, k);
+		const double nrm = sqrt(wave_sum(v * v));
+		if (!(nrm > 0.0))
+			continue;
+		const double beta = (alpha >= 0.0) ? -nrm : nrm;
+		if (lane == k)
+			v = alpha - beta;
+		const double tk = 1.0 / (nrm * (nrm + fabs(alpha)));
+		for (int j = k + 1; j <= C; ++j) {
+			const double e = on ? W[(on ? lane : 0) * ldw + j] : 0.0;
+			const double d = wave_sum(v * e) * tk;
+			if (on)
+				W[lane * ldw + j] = fma(-d, v, e);
+		}
+		if (lane == k)
+			W[k * ldw + k] = beta;
+		wave_sync();
+	}
+	for (int i = C - 1; i >= 0; --i) {
+		double sacc = W[i * ldw + C];
+		for (int j = i + 1; j < C; ++j)
+			sacc = fma(-W[i * ldw + j], wv[j], sacc);
+		const double wi = sacc / W[i * ldw + i];
+		wave_sync();
+		if (lane == 0)
+			wv[i] = wi;
+		wave_sync();
+	}
+	if (lane < nz) {
+		double z = 0.0;
+		if (dual) {
+			for (int i = 0; i < m; ++i)
+				z = fma(M[i * nz + lane], wv[i], z);
+		} else {
+			z = wv[lane];
+		}
+		zout[lane] = z;
+	}
+	wave_sync();
+}
+
+// Returns true (and replaces l.x by the reference's x_k) if levels 0..k could be replayed.
+template <bool WBC>
+__device__ __forceinline__ bool ref_replay(const SolveArgs &a, const Lds &l, int inst, int k, int n, int nz_entry,
+					   const WbcCtx &wx, const int (&jc)[NR / 4], double *res2_out)
+{
+	const int lane = lane_id();
+	const int Gcap = (a.Ptot ? a.Ptot : 1) * a.ld;
+	const int tvcap = (LDV * a.n > a.ld * a.mmax) ? LDV * a.n : a.ld * a.mmax;
+	const int Scap = (CHUNK * SROW > XROWS * a.ld) ? CHUNK * SROW : XROWS * a.ld;
+	ldsd *xr = l.tmp, *zv = l.tmp + NR, *wv = l.tau;
+#ifdef HOQP_REPLAY_DEBUG
+#define RDBG(...) do { if (lane == 0) printf(__VA_ARGS__); } while (0)
+#else
+#define RDBG(...) do { } while (0)
+#endif
+	RDBG("[replay] inst %d k %d n %d nz_entry %d Gcap %d tvcap %d Scap %d\n", inst, k, n, nz_entry, Gcap, tvcap, Scap);
+	if (n >= NR)
+		return false;
+	wave_sync();
+	if (lane < NR)
+		xr[lane] = 0.0;
+	wave_sync();
+	const ldsd *Zr = l.G;
+	bool zident = true;  // Zr is the identity so far (no null tests on LDS pointers: offset 0 is a valid address)
+	int nzr = n, zoff = 0, slot = 0;
+	for (int j = 0; j <= k; ++j) {
+		int mj, pj;
+		if (WBC) {
+			mj = wbc_m(wx, j);
+			pj = wbc_p(wx, j);
+		} else {
+			mj = min(max(uni(a.m_inst ? a.m_inst[(size_t)inst * a.L + j] : a.m[j]), 0), a.m[j]);
+			pj = min(max(uni(a.p_inst ? a.p_inst[(size_t)inst * a.L + j] : a.p[j]), 0), a.p[j]);
+		}
+		if (nzr == 0)
+			break;
+		if (pj > 0) {  // an inequality-only level: the fast path's own step (it lies in the common range)
+			if (slot >= kReplaySteps)
+				return false;
+			if (lane < n)
+				xr[lane] += l.xstep[slot * NR + lane];
+			++slot;
+			wave_sync();
+			continue;
+		}
+		if (mj == 0)
+			continue;
+		if (j == k && nzr != nz_entry)
+			return false;  // the LU's rank decisions differ from the QR's: leave the fast answer
+		const int cmin = min(mj, nzr);
+		RDBG("[replay]  level %d m %d nzr %d\n", j, mj, nzr);
+		// TV: M (mj x nzr) and, for j < k, the kernel matrix (nzr x (nzr - rank), rank = mj unless deficient)
+		if (mj * nzr + (j < k ? nzr * (nzr - cmin) : 0) > tvcap || (mj + nzr) * (cmin + 1) > Scap || mj + nzr > kWave)
+			return false;
+		{
+			// M = A_j Zr -> TV (stride nzr),  r = b_j - A_j xr -> l.rhs
+			double bm[NR / 4][2];
+			load_bm_from(bm, n, nzr, nzr, Zr, xr, zident);
+			const ProjDst dst = {l.TV, nzr, l.rhs};
+			if (WBC) {
+				if (j == 0) {
+					WbcLevelSrc<0> src(wx, a.wprm, l, jc);
+					project_task_mfma(src, mj, nzr, bm, dst, l);
+				} else if (j == 2) {
+					WbcLevelSrc<2> src(wx, a.wprm, l, jc);
+					project_task_mfma(src, mj, nzr, bm, dst, l);
+				} else if (j == 3) {
+					WbcLevelSrc<3> src(wx, a.wprm, l, jc);
+					project_task_mfma(src, mj, nzr, bm, dst, l);
+				} else {
+					WbcLevelSrc<4> src(wx, a.wprm, l, jc);
+					project_task_mfma(src, mj, nzr, bm, dst, l);
+				}
+			} else {
+				TaskRowsSrc src = {a.A[j] + (size_t)inst * a.m[j] * a.n, a.b[j] + (size_t)inst * a.m[j], a.n, n};
+				project_task_mfma(src, mj, nzr, bm, dst, l);
+			}
+		}
+		lds_reg_solve(l.TV, l.rhs, mj, nzr, a.eps, l.S, wv, zv);
+		if (j == k) {  // |A_k x_k - b_k|^2 at the regularised optimum
+			double ri = 0.0;
+			if (lane < mj) {
+				ri = l.rhs[lane];
+				for (int q = 0; q < nzr; ++q)
+					ri = fma(-l.TV[lane * nzr + q], zv[q], ri);
+			}
+			*res2_out = wave_sum(ri * ri);
+		}
+		if (lane < n) {
+			double sx = xr[lane];
+			if (zident) {
+				sx += zv[lane];
+			} else {
+				for (int q = 0; q < nzr; ++q)
+					sx = fma(Zr[lane * nzr + q], zv[q], sx);
+			}
+			xr[lane] = sx;
+		}
+		wave_sync();
+		if (j < k) {
+			const int rank = uni(lds_fullpivlu(l.TV, mj, nzr, l.colpos));
+			const int dk = nzr - rank;
+			RDBG("[replay]  level %d rank %d\n", j, rank);
+			if (dk == 0) {
+				nzr = 0;
+				continue;
+			}
+			if (mj * nzr + nzr * dk > tvcap)
+				return false;
+			ldsd *K = l.TV + mj * nzr;
+			lds_lu_kernel(l.TV, nzr, rank, l.colpos, K);
+			const int newoff = (zident || zoff != 0) ? 0 : n * nzr;
+			if (newoff + n * dk > Gcap || (!zident && newoff == 0 && n * dk > zoff))
+				return false;
+			ldsd *Zn = l.G + newoff;
+			// Zn (n x dk) = Zr K; two lanes per row
+			{
+				const int row = lane >> 1, h = lane & 1;
+				if (row < n)
+					for (int q = h; q < dk; q += 2) {
+						double sacc = 0.0;
+						if (zident) {
+							sacc = K[row * dk + q];
+						} else {
+							for (int t = 0; t < nzr; ++t)
+								sacc = fma(Zr[row * nzr + t], K[t * dk + q], sacc);
+						}
+						Zn[row * dk + q] = sacc;
+					}
+			}
+			wave_sync();
+			Zr = Zn;
+			zident = false;
+			zoff = newoff;
+			nzr = dk;
+		}
+	}
+	wave_sync();
+	RDBG("[replay] done inst %d\n", inst);
+	if (lane < n)
+		l.x[lane] = xr[lane];
+	wave_sync();
+	return true;
+}
+
+// ---------------------------------------------------------------------------
 // one priority level (HoQpProblem constructor pipeline, ho_qp_problem.cpp:11-25)
 // ---------------------------------------------------------------------------
 // GATE: Q2 of the reference (levels without inequalities of their own ignore the stored rows,
@@ -1378,6 +1720,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 	const int Pg = (consider || keep_rows) ? Pn : 0;  // rows that take part in rotation / update
 	int iters = 0;
 	double level_res2 = 0.0;
+	double dmin_level = 1e300;  // smallest pivot of an unconstrained solve (conditioning estimate)
 
 	int rank = 0;
 	double yi = 0.0;	 // lane i holds y_i (rotated coordinates)
@@ -1395,27 +1738,28 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 	// ---- 1. project the task into the current null space (ConstructH/C/D/FVector,
 	//         ho_qp_problem.cpp:180-285, in factored form) ----
 	auto project = [&](bool doA, bool doD) {
+		const ProjDst dstT = {l.TV, ld, l.rhs}, dstG = {l.G + P * ld, ld, l.g + P};
 		if (WBC) {  // fused entry (n <= 30: always the matrix-core path)
 			double bm[NR / 4][2];
 			load_bm(bm, n, nz, ld, l);
 			if (k == 1) {
 				if (p > 0 && doD) {
 					WbcLevelSrc<1> src(wx, a.wprm, l, jc);
-					project_task_mfma(src, p, nz, ld, bm, false, P, l);
+					project_task_mfma(src, p, nz, bm, dstG, l);
 				}
 			} else if (m > 0 && doA) {
 				if (k == 0) {
 					WbcLevelSrc<0> src(wx, a.wprm, l, jc);
-					project_task_mfma(src, m, nz, ld, bm, true, 0, l);
+					project_task_mfma(src, m, nz, bm, dstT, l);
 				} else if (k == 2) {
 					WbcLevelSrc<2> src(wx, a.wprm, l, jc);
-					project_task_mfma(src, m, nz, ld, bm, true, 0, l);
+					project_task_mfma(src, m, nz, bm, dstT, l);
 				} else if (k == 3) {
 					WbcLevelSrc<3> src(wx, a.wprm, l, jc);
-					project_task_mfma(src, m, nz, ld, bm, true, 0, l);
+					project_task_mfma(src, m, nz, bm, dstT, l);
 				} else {
 					WbcLevelSrc<4> src(wx, a.wprm, l, jc);
-					project_task_mfma(src, m, nz, ld, bm, true, 0, l);
+					project_task_mfma(src, m, nz, bm, dstT, l);
 				}
 			}
 		} else if (nz < 32) {  // matrix-core path
@@ -1423,11 +1767,11 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 			load_bm(bm, n, nz, ld, l);
 			if (m > 0 && doA) {
 				TaskRowsSrc src = {a.A[k] + (size_t)inst * a.m[k] * nstore, a.b[k] + (size_t)inst * a.m[k], nstore, n};
-				project_task_mfma(src, m, nz, ld, bm, true, 0, l);
+				project_task_mfma(src, m, nz, bm, dstT, l);
 			}
 			if (p > 0 && doD) {
 				TaskRowsSrc src = {a.D[k] + (size_t)inst * a.p[k] * nstore, a.f[k] + (size_t)inst * a.p[k], nstore, n};
-				project_task_mfma(src, p, nz, ld, bm, false, P, l);
+				project_task_mfma(src, p, nz, bm, dstG, l);
 			}
 		} else {
 			double zc[NR];
@@ -1552,6 +1896,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 				load_Urow(Urow, 0, nz, l);
 				double z = tri_bwd(Urow, inv, sel(act, cl), nz);
 				const double dmin = wave_min(act ? fabs(l.rdiag[lane]) : 1e300);
+				dmin_level = dmin;
 				if (a.eps != 0.0 && a.eps > 1e-10 * dmin * dmin) {  // see ls_solve_reg
 					double Lrow[NR];
 					load_Lrow(Lrow, 0, nz, l);
@@ -1657,7 +2002,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 					}
 				}
 				wave_sync();
-				yi = ls_solve_reg(0, rank, 0, m, nunp, a.eps, ld, &level_res2, l);
+				yi = ls_solve_reg(0, rank, 0, m, nunp, a.eps, ld, &level_res2, l, &dmin_level);
 				have_y0 = true;
 			}
 		} else if (!consider) {
@@ -1984,7 +2329,28 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 		}
 		if (__ballot(nonfinite))
 			st.status |= HOQP_STATUS_NONFINITE;
+		// bookkeeping of the reference replay: a QP level with equality rows cannot be replayed; an
+		// inequality-only level is carried as its x step
+		if (consider) {
+			if (m > 0 || st.nskip >= kReplaySteps) {
+				st.replay_ok = 0;
+			} else {
+				if (lane < NR)
+					l.xstep[st.nskip * NR + lane] = (lane < n) ? l.S[lane] : 0.0;
+				++st.nskip;
+			}
+		}
 	}
+#ifndef HOQP_NO_REPLAY
+	if (__builtin_expect(a.eps != 0.0 && !consider && !keep_rows && st.replay_ok && m > 0 && rank > 0 && k > 0 &&
+				     a.eps > kReplayTau * dmin_level * dmin_level,
+			     0)) {
+		wave_sync();
+		double res2 = 0.0;
+		if (ref_replay<WBC>(a, l, inst, k, n, nz, wx, jc, &res2))
+			level_res2 = res2 + res_const;
+	}
+#endif
 	if (lane == 0) {
 		if (a.out.level_res)
 			a.out.level_res[(size_t)inst * a.L + k] = sqrt(level_res2);
@@ -2200,6 +2566,8 @@ __global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
 		return;
 	LevelState st;
 	st.status = 0;
+	st.replay_ok = 1;
+	st.nskip = 0;
 	WbcCtx wx = {};
 	int jc[NR / 4] = {-1, -1, -1, -1, -1, -1, -1, -1};
 	if (WBC) {

@@ -30,6 +30,8 @@ for mode, kw in (("reference", {}), ("paper", {}), ("paper", C5)):
         s.synchronize()
         o = {k: v.cpu().numpy() for k, v in out.items()}
         ref, rc = oracle.wbc_solve_batch(inp, oracle.default_cfg(mode), oracle.default_wbc_params(mode, **kw), threads=16)
+        lit, _ = oracle.wbc_solve_batch(inp, oracle.default_cfg(mode, solver="literal"), oracle.default_wbc_params(mode, **kw), threads=16)
+        lit_over = int(((np.abs(lit["x"] - ref["x"]) / np.maximum(1.0, np.abs(ref["x"]))).max(axis=1) > 1e-6).sum())
         errs, over = {}, np.zeros(N, dtype=bool)
         for key, width in (("x", 30), ("qdd", 12), ("tau", 12), ("v", 40), ("level_res", 5)):
             r = ref[key][:, :width] if key == "v" else ref[key]
@@ -48,6 +50,6 @@ for mode, kw in (("reference", {}), ("paper", {}), ("paper", C5)):
         bad += not ok
         print(f"{mode:9s}{'/C5' if kw else ''} {kind:6s} N={N} rc={rc} worst={worst:.2e} {errs} gpu_status!=0:{nst} oracle_status!=0:{nref} "
               f"flag_diff:{flag_diff} over_1e-6:{int(over.sum())} of {N} (indices {np.flatnonzero(over)[:8].tolist()}) "
-              f"x_err/|x|_inf:{xrel:.2e} iters_max:{int(o['iters'].max())} {'OK' if ok else 'FAIL'}", flush=True)
+              f"x_err/|x|_inf:{xrel:.2e} literal_oracle_over_1e-6:{lit_over} iters_max:{int(o['iters'].max())} {'OK' if ok else 'FAIL'}", flush=True)
 print("ALL OK" if bad == 0 else f"{bad} case(s) FAILED")
 sys.exit(1 if bad else 0)
