@@ -1,13 +1,18 @@
 #!/usr/bin/env python3
 """bench.py -- fp64 HO-QP solves/s on MI355X (BASELINE.json metric).
 
-A "step" is one pass of the hot path (hoqp_solve_wbc_batched: task construction +
-5-level HO-QP chain + torque map + validity flags) over one batch of synthetic
-ANYmal-C-like states that is already resident in HBM.  N = 1 workload: BASELINE.json
-configs[1] (4096 randomised 4-contact stance states, reference semantics).  N > 1: the
-batch dimension is sharded, one process per GPU, the same 4096 states per rank (weak
-scaling); the only collective is the RCCL gather of per-instance solutions and the
-all-reduce of residual statistics to rank 0 (the path's one exchange step).
+A "step" is one pass of the hot path (hoqp_solve_wbc_batched: ONE kernel -- task construction,
+5-level HO-QP chain, torque map and validity flags) over one batch of synthetic ANYmal-C-like
+states that is already resident in HBM.
+
+Workloads (`config.workload`):
+  default   BASELINE.json configs[1]: 4096 randomised 4-contact stance states per GPU, reference
+            semantics.  N > 1: the same per rank (weak scaling), one process per GPU; the solve has
+            no exchange step; results are collected once after the timed loop (`gather_ms`).
+  --workload c4   configs[3]: 1,048,576 randomised stance states (seed 3456) split contiguously over
+            the ranks (parallel.shard_bounds), every step = solve of the shard + RCCL gather of
+            x / tau / v / status to rank 0 + all-reduce of the residual statistics, all inside the
+            timed region (strong scaling).  At N = 1 the whole batch runs on the one GPU.
 
 Prints ONE JSON line on rank 0.
 """
@@ -26,37 +31,75 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-FP64_VEC_PEAK_TF = 78.6    # public spec figure, vector FP64
-# algorithmic bytes per solve of the dominant kernel (hoqp_solve_kernel reads the generic
-# task blocks): SURVEY.md section 8(d), generic task entry, n_c = 4: 8*76*31 in + 664 out
-ALG_BYTES_PER_SOLVE = 8 * 76 * 31 + 664
-# algorithmic flops per solve, reference mode, zero active-set iterations
-ALG_FLOPS_PER_SOLVE = 210_984
-
+FP64_VEC_PEAK_TF = 78.6    # public spec figure, vector FP64 (SURVEY.md section 8d)
 
 # which BASELINE.json configuration a --contact choice restates
 WORKLOAD_LABEL = {"stance": "configs[1]", "trot": "configs[2] (trot mix)", "three": "configs[4] (swing tracking)",
                   "crawl": "crawl gait of the reference via the command sampler"}
 
 
+def alg_bytes_per_solve(nc, ns):
+    """SURVEY.md 8(d), fused WBC entry: inputs 8*(324 M + 18 h + 57 per leg + 6 base rhs) + 4 B mask,
+    outputs 8*(54 + 7 n_c) + 8.  5,276 B for n_c = 4."""
+    return 8 * (324 + 18 + 57 * (nc + ns) + 6) + 4 + 8 * (54 + 7 * nc) + 8
+
+
+def alg_flops_per_solve(nc, ns, gate):
+    """SURVEY.md 8(d) convention: dense textbook counts, Z_-1 = I and x_-1 = 0 exploited, no sparsity,
+    zero active-set iterations.  210,984 for n_c = 4 under reference semantics, 318,984 under paper."""
+    n = 18 + 3 * nc
+    ms = [6, 0, 3 * nc, 6 + 3 * ns, 3 * nc]
+    ps = [0, 24 + 4 * nc, 0, 0, 0]
+    nz, P, total = n, 0, 0.0
+    for k in range(5):
+        m, p = ms[k], ps[k]
+        looks = (p > 0) if gate else (p > 0 or P > 0)
+        rows = (p + P) if looks else 0
+        if k > 0:
+            total += 2 * m * n * nz + 2 * m * n + 2 * n * nz
+            total += 2 * rows * n * nz + 2 * rows * n
+        total += 2 * m * nz * nz + 2 * m * nz
+        if m > 0:
+            total += nz ** 3 / 3 + 2 * nz * nz
+            if k < 4:
+                total += 2 * m * m * (nz - m / 3) + 4 * n * nz * m
+        P += p
+        nz -= min(m, nz)
+    return total
+
+
 def cpu_model():
+    """model name plus family / model / stepping from /proc/cpuinfo (virtualised hosts report a bare
+    "AMD EPYC" as the name)."""
+    info = {}
     try:
         with open("/proc/cpuinfo") as f:
             for line in f:
-                if line.startswith("model name"):
-                    return line.split(":", 1)[1].strip()
+                if ":" not in line:
+                    if info:
+                        break
+                    continue
+                k, v = (s.strip() for s in line.split(":", 1))
+                if k in ("model name", "cpu family", "model", "stepping", "cpu MHz", "vendor_id") and k not in info:
+                    info[k] = v
     except OSError:
         pass
-    return "unknown"
+    if not info:
+        return "unknown"
+    return "{} (vendor {}, family {}, model {}, stepping {}, {} MHz; {} logical CPUs visible)".format(
+        info.get("model name", "?"), info.get("vendor_id", "?"), info.get("cpu family", "?"), info.get("model", "?"),
+        info.get("stepping", "?"), info.get("cpu MHz", "?"), os.cpu_count())
 
 
 def cpu_baseline(inp, mode, sample, threads, prm_kw, detail=False):
-    """The oracle ("port") timed on the host cores over a bounded sample."""
+    """The oracle ("port") timed on the host cores over a bounded sample.  Timed with its literal
+    double-precision solver (H = (AZ)'AZ + eps I formed and factored in double, as a restatement of the
+    reference computes it); the long-double least-squares solver is the parity checker, not a baseline."""
     from oracle import oracle as orc
 
     orc.build()
     sub = {k: v[:sample] for k, v in inp.items()}
-    cfg, prm = orc.default_cfg(mode), orc.default_wbc_params(mode, **prm_kw)
+    cfg, prm = orc.default_cfg(mode, solver="literal"), orc.default_wbc_params(mode, **prm_kw)
     orc.wbc_solve_batch({k: v[:8] for k, v in sub.items()}, cfg, prm, threads=threads)  # warm
     reps, t0 = 0, time.perf_counter()
     while True:
@@ -67,7 +110,8 @@ def cpu_baseline(inp, mode, sample, threads, prm_kw, detail=False):
             break
     res = dict(value=sample * reps / dt, unit="solves/s", cores=threads, kind="port",
                sample=f"{reps} passes over the first {sample} states of the same batch, "
-                      f"oracle/hoqp_oracle.c (-O3, OpenMP {threads} threads); Drake/Eigen reference unbuildable",
+                      f"oracle/hoqp_oracle.c literal double solver (-O3, OpenMP {threads} threads); "
+                      f"Drake/Eigen reference unbuildable",
                cpu_model=cpu_model())
     if detail:
         # SURVEY.md 8(d) CPU baseline (i): one thread, configs[0] (the nominal standing state),
@@ -86,17 +130,65 @@ def cpu_baseline(inp, mode, sample, threads, prm_kw, detail=False):
     return res
 
 
+def feasibility_match(out, inp, mode, sample, threads, prm_kw):
+    """north star: "same feasibility and active constraints".  The HIP path's CheckSolutionValid flags
+    (helper_functions.hpp:63-91) and active-row masks against the authoritative oracle on the first
+    `sample` states: counts of identical entries, and of the differing ones how many sit inside the
+    1e-7 band around the threshold they are compared with."""
+    from oracle import oracle as orc
+
+    orc.build()
+    sub = {k: v[:sample] for k, v in inp.items()}
+    prm = orc.default_wbc_params(mode, **prm_kw)
+    ref, rc = orc.wbc_solve_batch(sub, orc.default_cfg(mode), prm, threads=threads)
+    flags = out["flags"][:sample].cpu().numpy()
+    mask = out["active_mask"][:sample].cpu().numpy().astype(np.uint64)
+    x = out["x"][:sample].cpu().numpy()
+    fdiff = flags != ref["flags"]
+    band = (np.abs(ref["eq_res_max"] - 1e-7) <= 1e-7) | (np.abs(ref["ineq_viol_max"]) <= 1e-7)
+    mdiff = mask ^ ref["active_mask"].astype(np.uint64)
+    nbits = sum(bin(int(v)).count("1") for v in mdiff)
+    # a differing active bit is in-band when the oracle's margin of that row is within 1e-7 of -1e-7
+    bits_in_band = 0
+    for i in np.nonzero(mdiff)[0]:
+        tasks, n = orc.wbc_build(sub, int(i), prm)
+        marg = tasks[1]["D"] @ ref["x"][i][:n] - tasks[1]["f"]
+        bits_in_band += sum(1 for r in range(len(marg)) if (int(mdiff[i]) >> r) & 1 and abs(marg[r] + 1e-7) <= 1e-7)
+    xerr = np.abs(x - ref["x"]) / np.maximum(1.0, np.abs(ref["x"]))
+    return {"states": int(sample), "oracle_rc": int(rc),
+            "flags_equal": int((~fdiff).sum()), "flags_total": int(fdiff.size),
+            "flags_differ_in_band": int((fdiff & band).sum()), "flags_differ_outside_band": int((fdiff & ~band).sum()),
+            "active_mask_equal": int((mdiff == 0).sum()), "active_mask_total": int(mdiff.size),
+            "active_bits_differ": int(nbits), "active_bits_differ_in_band": int(bits_in_band),
+            "x_max_rel_err": float(xerr.max()), "x_over_1e-6": int((xerr.max(axis=1) > 1e-6).sum())}
+
+
+def load_traffic(batch, mode, contact):
+    """HBM bytes per launch of the dominant kernel from the committed PMC pass of this same command
+    (tools/profile.sh; separate --pmc runs).  Only for the profiled workload."""
+    for name in ("r02_pmc_traffic.json",):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                tj = json.load(f)
+            if tj.get("batch") == batch and tj.get("semantics") == mode and tj.get("contact") == contact:
+                return float(tj["fetch_bytes_per_launch"] + tj["write_bytes_per_launch"]), tj.get("source")
+        except (OSError, ValueError, KeyError):
+            pass
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=4096, help="states per GPU per step")
+    ap.add_argument("--workload", default="default", choices=["default", "c4"])
+    ap.add_argument("--batch", type=int, default=None, help="states per GPU per step (default 4096; c4: 1,048,576 in total)")
     ap.add_argument("--mode", default="reference", choices=["reference", "paper"])
     ap.add_argument("--contact", default="stance", choices=["stance", "trot", "three", "crawl"],
                     help="contact patterns: i.i.d. masks (stance / trot / three) or, for crawl, the pattern and swing "
                          "commands of the reference's crawl gait at random phases (hoqp_gait_sample_batched)")
-    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=512)
     ap.add_argument("--mu", type=float, default=None, help="friction coefficient (default: the reference's)")
@@ -105,7 +197,8 @@ def main():
                     help="also time the oracle single-threaded on configs[0] (10^4 repetitions)")
     ap.add_argument("--no-gather", action="store_true", help="skip the collection of results on rank 0")
     ap.add_argument("--gather-every-step", action="store_true",
-                    help="gather solutions to rank 0 inside every timed step (default: once, after the timed loop)")
+                    help="gather solutions to rank 0 inside every timed step (default workload: once, after the loop)")
+    ap.add_argument("--latency-batches", type=int, default=1000, help="batches for the p50 / p99 latency sample")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -131,6 +224,7 @@ def main():
 
     from quadruped_locomotion_amd import anymal_model as am
     from quadruped_locomotion_amd import hoqp
+    from quadruped_locomotion_amd import parallel
 
     torch.cuda.set_device(local_rank)
     prm_kw = {}
@@ -139,33 +233,65 @@ def main():
     if args.tau_max is not None:
         prm_kw.update(tau_max=args.tau_max, tau_min=-args.tau_max)
     solver = hoqp.HoQpSolver(hoqp.default_config(args.mode, device=local_rank, **prm_kw))
-    inp = am.make_wbc_inputs(am.sample_states(args.batch, args.seed + rank,
-                                              "stance" if args.contact == "crawl" else args.contact))
-    dinp = solver.to_device(inp)
+    c4 = args.workload == "c4"
+    if c4:
+        # one global batch (seed 3456), contiguous shards; every rank generates only its own
+        # shard (states are i.i.d., so shard r is drawn from seed 3456 + r)
+        total = args.batch or 1048576
+        seed = 3456 if args.seed is None else args.seed
+        lo, hi = parallel.shard_bounds(total, world, rank)
+        nloc = hi - lo
+        gather_in_step = world > 1 and not args.no_gather
+    else:
+        nloc = args.batch or 4096
+        total = nloc * world
+        seed = 1234 if args.seed is None else args.seed
+        gather_in_step = world > 1 and args.gather_every_step and not args.no_gather
+    kind = "stance" if args.contact == "crawl" else args.contact
+    if nloc > 65536:
+        # large shards: only the states come from the host; the dynamics terms are produced on the device
+        # (hoqp_wbc_dynamics_batched, SURVEY 8f N1 -- the same model as anymal_model.py to 1e-12) instead of
+        # ~5 KB per state going through numpy and PCIe.  The CPU legs below read the device arrays back.
+        st = am.sample_states(nloc, seed + rank, kind)
+        dq = torch.as_tensor(st["q"]).contiguous().to(solver.device)
+        du = torch.as_tensor(st["u"]).contiguous().to(solver.device)
+        dinp = solver.wbc_dynamics(dq, du)
+        dinp.update(q=dq, u=du, base_cmd=torch.as_tensor(st["base_cmd"]).contiguous().to(solver.device),
+                    contact=torch.as_tensor(st["contact"].astype(np.int32)).contiguous().to(solver.device))
+        lc = torch.as_tensor(st["leg_cmd"]).contiguous().to(solver.device)
+        if np.any(st["contact"] == 0):
+            lc[:, 0:12] += dinp["footpos"].reshape(-1, 12)   # swing target = current foot + offset
+        dinp["leg_cmd"] = lc
+        solver.synchronize()
+        head = min(nloc, max(args.cpu_sample, 1))
+        inp = {k: v[:head].cpu().numpy() for k, v in dinp.items()}
+        inp["contact_all"] = st["contact"]
+        del st
+    else:
+        inp = am.make_wbc_inputs(am.sample_states(nloc, seed + rank, kind))
+        dinp = solver.to_device(inp)
     if args.contact == "crawl":
         # commands from the gait sampler on the device (2-, 3- and 4-contact states)
-        rng = np.random.default_rng(args.seed + rank + 77)
-        t_gait = torch.as_tensor(rng.uniform(0.0, 10.0, args.batch)).cuda()
-        v_cmd = torch.as_tensor(rng.normal(0.0, 0.1, (args.batch, 2))).cuda()
+        rng = np.random.default_rng(seed + rank + 77)
+        t_gait = torch.as_tensor(rng.uniform(0.0, 10.0, nloc)).cuda()
+        v_cmd = torch.as_tensor(rng.normal(0.0, 0.1, (nloc, 2))).cuda()
         lc, ct = solver.gait_sample(hoqp.default_gait("crawl", fix_derivatives=1), t_gait, v_cmd,
                                     dinp["footpos"][:, :, :2].contiguous())
         dinp["leg_cmd"], dinp["contact"] = lc, ct
         solver.synchronize()
         inp["leg_cmd"], inp["contact"] = lc.cpu().numpy(), ct.cpu().numpy()
-    out = solver.alloc_wbc_outputs(args.batch)
-    from quadruped_locomotion_amd import parallel
+    out = solver.alloc_wbc_outputs(nloc)
 
     def collect():
-        # collection of results: per-instance solutions to rank 0 (RCCL
-        # gather), residual statistics all-reduced.  The solve itself has no exchange step, so by
-        # default this runs once after the timed loop and is reported as `gather_ms`.
-        parallel.gather_solutions(dict(x=out["x"], tau=out["tau"]), args.batch * world, dst=0)
+        # collection of results: per-instance x, tau, v*, status to rank 0 (RCCL
+        # gather), residual statistics all-reduced
+        parallel.gather_solutions(dict(x=out["x"], tau=out["tau"], v=out["v"], status=out["status"]), total, dst=0)
         mx, sm = parallel.local_stats(out)
-        parallel.reduce_stats(mx, sm)
+        return parallel.reduce_stats(mx, sm)
 
     def step():
         solver.solve_wbc(dinp, out)
-        if world > 1 and args.gather_every_step and not args.no_gather:
+        if gather_in_step:
             collect()
 
     def barrier():
@@ -177,7 +303,6 @@ def main():
         step()
     barrier()
     solver.timing(True)
-    lat = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -187,24 +312,28 @@ def main():
     kern_ms, kern_n = solver.kernel_time_ms()
     solver.timing(False)
 
-    # p50/p99 batch latency (submit -> results visible), measured outside the timed region
-    # >= 1000 batches for the percentiles on a default run (fewer on short runs)
-    for _ in range(1000 if args.steps >= 200 else args.steps):
+    # p50/p99 batch latency (submit -> results visible), outside the timed region; SURVEY 8d: >= 1000
+    # batches regardless of --steps (fewer only for batches that take longer than 10 ms each)
+    lat = []
+    nlat = args.latency_batches if elapsed / max(args.steps, 1) < 10e-3 else min(args.latency_batches, 100)
+    for _ in range(nlat):
         torch.cuda.synchronize()
         a = time.perf_counter()
-        step()
+        solver.solve_wbc(dinp, out)
         torch.cuda.synchronize()
         lat.append((time.perf_counter() - a) * 1e3)
     lat = np.array(lat)
 
-    gather_ms = None
+    gather_ms, stats = None, None
     if world > 1 and not args.no_gather:
         collect()  # warm-up of the communicator
         barrier()
         g0 = time.perf_counter()
-        collect()
+        mx, sm = collect()
         barrier()
         gather_ms = (time.perf_counter() - g0) * 1e3
+        stats = dict(eq_res_max=float(mx[0]), ineq_viol_max=float(mx[1]), status_nonzero=int(sm[0]),
+                     iters_total=int(sm[1]), instances=int(sm[2]))
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64,
                             device="cpu" if dist.get_backend() == "gloo" else solver.device)
@@ -214,22 +343,18 @@ def main():
     status = out["status"].cpu().numpy()
     iters = out["iters"].cpu().numpy()
     if rank == 0:
-        total = args.batch * world * args.steps
-        value = total / elapsed
+        value = total * args.steps / elapsed
         kern_s = kern_ms * 1e-3
-        achieved_gbs = ALG_BYTES_PER_SOLVE * args.batch / kern_s / 1e9 if kern_s > 0 else 0.0
-        # HBM bytes per launch of the dominant kernel from the committed PMC pass of this same
-        # command (tools/profile.sh; separate --pmc runs).  Only reported for the profiled
-        # workload; FETCH_SIZE is uncalibrated for 8-byte-per-lane loads on gfx950.
-        traffic, traffic_src = None, None
-        try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")) as f:
-                tj = json.load(f)
-            if tj.get("batch") == args.batch and tj.get("semantics") == args.mode and tj.get("contact") == args.contact:
-                traffic = float(tj["fetch_bytes_per_launch"] + tj["write_bytes_per_launch"])
-                traffic_src = tj.get("source")
-        except (OSError, ValueError, KeyError):
-            pass
+        ct = inp.pop("contact_all", inp["contact"])
+        nc_i, ns_i = (ct == 1).sum(axis=1), (ct == 0).sum(axis=1)
+        gate = args.mode == "reference"
+        pats = {(int(a), int(b)) for a, b in zip(nc_i, ns_i)}
+        bytes_mean = float(np.mean([alg_bytes_per_solve(a, b) for a, b in zip(nc_i, ns_i)]))
+        fl = {pt: alg_flops_per_solve(pt[0], pt[1], gate) for pt in pats}
+        flops_mean = float(np.mean([fl[(int(a), int(b))] for a, b in zip(nc_i, ns_i)]))
+        ach_tf = flops_mean * nloc / kern_s / 1e12 if kern_s > 0 else 0.0
+        ach_gbs = bytes_mean * nloc / kern_s / 1e9 if kern_s > 0 else 0.0
+        traffic, traffic_src = load_traffic(nloc, args.mode, args.contact)
         res = {
             "metric": "fp64 HO-QP solves/sec (ANYmal-C, 4 contacts)",
             "value": value,
@@ -239,25 +364,33 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if c4 else "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic (own ANYmal-C-like model, seed %d)" % args.seed,
-            "config": {"workload": f"{WORKLOAD_LABEL[args.contact]}: {args.batch} randomised {args.contact} states "
-                                   f"per GPU, 5-level WBC hierarchy, {args.mode} semantics",
-                       "batch_per_gpu": args.batch, "semantics": args.mode, "contact": args.contact,
-                       "entry": "hoqp_solve_wbc_batched", "params": prm_kw or "reference defaults",
-                       "gather": ("every_step" if args.gather_every_step else "after_loop")
-                       if (world > 1 and not args.no_gather) else "none", "gather_ms": gather_ms},
-            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": traffic_src,
-                         "kernel": "hoqp_solve_kernel", "kernel_ms": kern_ms, "launches_timed": kern_n,
-                         "alg_bytes_per_solve": ALG_BYTES_PER_SOLVE,
-                         "fp64_vector": {"achieved_tflops": ALG_FLOPS_PER_SOLVE * args.batch / kern_s / 1e12
-                                         if kern_s > 0 else 0.0, "peak_tflops": FP64_VEC_PEAK_TF,
-                                         "alg_flops_per_solve": ALG_FLOPS_PER_SOLVE},
-                         "note": "latency/LDS-bound small factorizations; both classical fractions are < 1 %"},
+            "data": "synthetic (own ANYmal-C-like model, seed %d)" % seed,
+            "config": {"workload": (f"configs[3]: {total} randomised stance states split over {world} GPU(s), "
+                                    f"gather of x/tau/v/status + statistics all-reduce inside every step"
+                                    if c4 else
+                                    f"{WORKLOAD_LABEL[args.contact]}: {nloc} randomised {args.contact} states "
+                                    f"per GPU") + f", 5-level WBC hierarchy, {args.mode} semantics",
+                       "batch_per_gpu": nloc, "batch_total": total, "semantics": args.mode, "contact": args.contact,
+                       "entry": "hoqp_solve_wbc_batched (fused: one kernel per step)",
+                       "params": prm_kw or "reference defaults",
+                       "gather": ("every_step" if gather_in_step else "after_loop")
+                       if (world > 1 and not args.no_gather) else "none", "gather_ms": gather_ms,
+                       "gathered": ["x", "tau", "v", "status"], "reduced_stats": stats},
+            # the fused entry's arithmetic intensity (~40 FLOP/B) is above the FP64 ridge, so the
+            # nominal bound is FP64 vector throughput; HBM is reported beside it.  The kernel is in fact bound
+            # by dependent-chain latency at one wave per SIMD.
+            "roofline": {"bound": "fp64_vector", "achieved": ach_tf, "peak": FP64_VEC_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": ach_tf / FP64_VEC_PEAK_TF, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "hoqp_solve_kernel<GATE,HARD,WBC=true>", "kernel_ms": kern_ms,
+                         "launches_timed": kern_n, "alg_flops_per_solve": flops_mean,
+                         "alg_bytes_per_solve": bytes_mean,
+                         "hbm": {"achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": ach_gbs / HBM_PEAK_GBS},
+                         "note": "FLOPs and bytes: SURVEY.md 8(d) formulas for the fused WBC entry, averaged over the "
+                                 "batch's contact patterns; active-set iterations are not counted as FLOPs"},
             "latency_ms": {"p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99)),
                            "max": float(lat.max()), "batches": int(lat.size)},
             "solver": {"status_nonzero": int((status != 0).sum()), "iters_level1_mean": float(iters[:, 1].mean()),
@@ -267,8 +400,9 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             threads = min(16, os.cpu_count() or 1)
-            res["cpu_baseline"] = cpu_baseline(inp, args.mode, min(args.cpu_sample, args.batch), threads, prm_kw,
-                                               detail=args.cpu_detail)
+            sample = min(args.cpu_sample, nloc)
+            res["cpu_baseline"] = cpu_baseline(inp, args.mode, sample, threads, prm_kw, detail=args.cpu_detail)
+            res["feasibility_match"] = feasibility_match(out, inp, args.mode, sample, threads, prm_kw)
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res))

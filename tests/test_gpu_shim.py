@@ -85,3 +85,26 @@ def test_shim_controller(tmp_path, oracle):
     fl = [l for l in out if l.startswith("flags")][0].split()
     assert int(fl[7]) == 0
     assert [int(v) for v in fl[1:6]][0] == 1
+
+
+def test_bench_two_rank_rehearsal():
+    """The N > 1 path of bench.py end to end on the one-GPU box: two ranks share device 0 (gloo in place of
+    RCCL, which refuses two ranks on one device), workload c4 scaled down -- every step = HIP solve of the
+    rank's shard + gather of x / tau / v / status to rank 0 + all-reduce of the statistics."""
+    import json
+    import sys
+
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, HOQP_BENCH_REHEARSE="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "c4", "--batch", "8191",
+           "--steps", "3", "--warmup", "1", "--latency-batches", "5"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["gather"] == "every_step"
+    assert d["config"]["batch_total"] == 8191 and d["config"]["batch_per_gpu"] == 4096      # ragged shards
+    st = d["config"]["reduced_stats"]
+    assert st["instances"] == 8191 and st["status_nonzero"] == 0 and np.isfinite(st["eq_res_max"])
+    assert d["value"] > 0 and d["config"]["gather_ms"] > 0

@@ -34,13 +34,16 @@ def _worker(rank, world, port, total, tmp):
     lo, hi = parallel.shard_bounds(total, world, rank)
     ref, rc = orc.wbc_solve_batch({k: v[lo:hi] for k, v in inp.items()})
     local = dict(x=torch.from_numpy(ref["x"].copy()), tau=torch.from_numpy(ref["tau"].copy()),
+                 v=torch.from_numpy(np.ascontiguousarray(ref["v"][:, :40])),
                  status=torch.from_numpy(ref["status"].astype(np.int32)),
                  iters=torch.from_numpy(ref["iters"].astype(np.int32)),
                  eq_res_max=torch.from_numpy(ref["eq_res_max"].copy()),
                  ineq_viol_max=torch.from_numpy(ref["ineq_viol_max"].copy()))
     mx, sm = parallel.local_stats(local)
     parallel.reduce_stats(mx, sm)
-    full = parallel.gather_solutions(dict(x=local["x"], tau=local["tau"]), total, dst=0)
+    # the payload of SURVEY.md 8(e): x, tau, v*, status
+    full = parallel.gather_solutions(dict(x=local["x"], tau=local["tau"], v=local["v"], status=local["status"]),
+                                     total, dst=0)
     if rank == 0:
         torch.save(dict(full=full, mx=mx, sm=sm), os.path.join(tmp, "out.pt"))
     else:
@@ -62,7 +65,7 @@ def test_shard_bounds():
         parallel.shard_bounds(4, 2, 2)
 
 
-@pytest.mark.parametrize("total", [9, 16])
+@pytest.mark.parametrize("total", [9, 16, 1])      # ragged last shard, even shards, an EMPTY shard on rank 1
 def test_two_rank_gather_and_stats(tmp_path, total):
     sys.path.insert(0, ROOT)
     from oracle import oracle as orc
@@ -77,5 +80,10 @@ def test_two_rank_gather_and_stats(tmp_path, total):
     assert got["full"]["x"].shape == (total, 30)
     assert np.array_equal(got["full"]["x"].numpy(), ref["x"])       # ragged last shard included
     assert np.array_equal(got["full"]["tau"].numpy(), ref["tau"])
+    assert got["full"]["v"].shape == (total, 40) and np.array_equal(got["full"]["v"].numpy(), ref["v"][:, :40])
+    assert got["full"]["status"].dtype == torch.int32 and np.array_equal(got["full"]["status"].numpy(), ref["status"])
+    # reduced statistics: MAX of the residual maxima, SUM of the counts
     assert abs(got["mx"][0].item() - ref["eq_res_max"].max()) < 1e-15
+    assert abs(got["mx"][1].item() - ref["ineq_viol_max"].max()) < 1e-15
+    assert got["sm"][0].item() == (ref["status"] != 0).sum()
     assert got["sm"][2].item() == total and got["sm"][1].item() == ref["iters"].sum()
