@@ -199,6 +199,9 @@ def main():
     ap.add_argument("--gather-every-step", action="store_true",
                     help="gather solutions to rank 0 inside every timed step (default workload: once, after the loop)")
     ap.add_argument("--latency-batches", type=int, default=1000, help="batches for the p50 / p99 latency sample")
+    ap.add_argument("--skip-unread-slack", action="store_true",
+                    help="NOT the headline: HOQP_OPT_SKIP_UNREAD_SLACK_LEVELS with v == NULL (the torque / friction "
+                         "level's QP is not solved; x, tau and flags unchanged to rounding)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -232,7 +235,10 @@ def main():
         prm_kw["mu"] = args.mu
     if args.tau_max is not None:
         prm_kw.update(tau_max=args.tau_max, tau_min=-args.tau_max)
-    solver = hoqp.HoQpSolver(hoqp.default_config(args.mode, device=local_rank, **prm_kw))
+    cfg_kw = dict(prm_kw)
+    if args.skip_unread_slack:
+        cfg_kw["options"] = hoqp.OPT_SKIP_UNREAD_SLACK_LEVELS
+    solver = hoqp.HoQpSolver(hoqp.default_config(args.mode, device=local_rank, **cfg_kw))
     c4 = args.workload == "c4"
     if c4:
         # one global batch (seed 3456), contiguous shards; every rank generates only its own
@@ -281,11 +287,16 @@ def main():
         solver.synchronize()
         inp["leg_cmd"], inp["contact"] = lc.cpu().numpy(), ct.cpu().numpy()
     out = solver.alloc_wbc_outputs(nloc)
+    if args.skip_unread_slack:
+        out["v"] = None
 
     def collect():
         # collection of results: per-instance x, tau, v*, status to rank 0 (RCCL
         # gather), residual statistics all-reduced
-        parallel.gather_solutions(dict(x=out["x"], tau=out["tau"], v=out["v"], status=out["status"]), total, dst=0)
+        payload = dict(x=out["x"], tau=out["tau"], status=out["status"])
+        if out["v"] is not None:
+            payload["v"] = out["v"]
+        parallel.gather_solutions(payload, total, dst=0)
         mx, sm = parallel.local_stats(out)
         return parallel.reduce_stats(mx, sm)
 
@@ -374,7 +385,9 @@ def main():
                                     f"{WORKLOAD_LABEL[args.contact]}: {nloc} randomised {args.contact} states "
                                     f"per GPU") + f", 5-level WBC hierarchy, {args.mode} semantics",
                        "batch_per_gpu": nloc, "batch_total": total, "semantics": args.mode, "contact": args.contact,
-                       "entry": "hoqp_solve_wbc_batched (fused: one kernel per step)",
+                       "entry": "hoqp_solve_wbc_batched (fused: one kernel per step)" +
+                                (" with HOQP_OPT_SKIP_UNREAD_SLACK_LEVELS and v == NULL -- NOT the headline configuration"
+                                 if args.skip_unread_slack else ""),
                        "params": prm_kw or "reference defaults",
                        "gather": ("every_step" if gather_in_step else "after_loop")
                        if (world > 1 and not args.no_gather) else "none", "gather_ms": gather_ms,

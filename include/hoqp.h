@@ -61,7 +61,17 @@ typedef struct {
 	 * ho_qp_controller.cpp:191-192, 224-225, 259-260 */
 	double mu, tau_max, tau_min;
 	double kp_swing, kv_swing, kp_base, kv_base, kv_rot;
+	int options;	/* HOQP_OPT_* bitmask, 0 = bit-compatible default */
 } hoqp_config;
+
+/* Skip a level that has only inequality rows when nothing can observe its result: under Q2
+ * (ho_qp_problem.cpp:297-298) no later level looks at its rows, and the caller passed v == NULL, so its
+ * slacks are not read either.  Such a level only moves x inside the null space of the levels above it; when
+ * the hierarchy ends with an empty null space (the WBC hierarchy) the final x, tau and validity flags are
+ * the same to ~1e-7 relative (the eps_ bias of the later levels depends on where in that null space x sits),
+ * while x_levels of the skipped level keep the previous level's x.  In the
+ * reference's WBC hierarchy this removes the torque / friction level's QP (about 30 % of the solve). */
+#define HOQP_OPT_SKIP_UNREAD_SLACK_LEVELS 0x01
 
 /* Replaces: the compile-time constants of HoQpController / HoQpProblem. */
 void hoqp_default_config(hoqp_config *cfg);

@@ -352,6 +352,7 @@ static void fill_common(hoqp_handle *h, SolveArgs *a)
 	a->slack_quirk = (h->cfg.semantics & HOQP_Q3_SLACK_ORDER) ? 1 : 0;
 	a->max_iter = h->cfg.max_iter > 0 ? h->cfg.max_iter : 200;
 	a->eps = h->cfg.eps;
+	a->skip_unread = (h->cfg.options & HOQP_OPT_SKIP_UNREAD_SLACK_LEVELS) ? 1 : 0;
 	// which levels look at stored inequality rows, and does any of them also carry equality rows?
 	a->use_bl = 0;
 	a->any_hard = 0;

@@ -39,6 +39,7 @@ struct SolveArgs {
 	const double *A[HOQP_MAX_LEVELS], *b[HOQP_MAX_LEVELS], *D[HOQP_MAX_LEVELS], *f[HOQP_MAX_LEVELS];
 	const int *n_inst, *m_inst, *p_inst;
 	int gate_prior, slack_quirk, max_iter;
+	int skip_unread;  // HOQP_OPT_SKIP_UNREAD_SLACK_LEVELS
 	double eps;
 	hoqp_result_batch out;
 	int Ptot;  // storage extent of stacked inequality rows (<= 64)
@@ -1739,7 +1740,19 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 	//         ho_qp_problem.cpp:180-285, in factored form) ----
 	auto project = [&](bool doA, bool doD) {
 		const ProjDst dstT = {l.TV, ld, l.rhs}, dstG = {l.G + P * ld, ld, l.g + P};
-		if (WBC) {  // fused entry (n <= 30: always the matrix-core path)
+		if (WBC && k == 4) {
+			// ConstructForceMinimizationTask: A = [0 I], b = 0, so A Z is rows 18.. of Z and A x the
+			// contact forces -- copied, not multiplied (the products are exact either way)
+			if (m > 0 && doA) {
+				for (int idx = lane; idx < m * nz; idx += kWave) {
+					const int r = idx / nz, j = idx - r * nz;
+					l.TV[r * ld + j] = l.Z[(kNU + r) * ld + j];
+				}
+				if (lane < m)
+					l.rhs[lane] = 0.0 - l.x[kNU + lane];
+				wave_sync();
+			}
+		} else if (WBC) {  // fused entry (n <= 30: always the matrix-core path)
 			double bm[NR / 4][2];
 			load_bm(bm, n, nz, ld, l);
 			if (k == 1) {
@@ -1754,11 +1767,8 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 				} else if (k == 2) {
 					WbcLevelSrc<2> src(wx, a.wprm, l, jc);
 					project_task_mfma(src, m, nz, bm, dstT, l);
-				} else if (k == 3) {
+				} else {  // k == 3 (level 4 is handled above)
 					WbcLevelSrc<3> src(wx, a.wprm, l, jc);
-					project_task_mfma(src, m, nz, bm, dstT, l);
-				} else {
-					WbcLevelSrc<4> src(wx, a.wprm, l, jc);
 					project_task_mfma(src, m, nz, bm, dstT, l);
 				}
 			}
@@ -2611,15 +2621,35 @@ __global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
 	}
 	if (lane < NR)
 		l.x[lane] = 0.0;
+	// Touch every cache line of the instance's M, J_foot, h and J_dot u now (one load per lane, one line
+	// of 16 doubles each): the levels read them one after the other, and each first touch would otherwise
+	// expose a full HBM round trip (~2 k cycles) to the only wave of the SIMD.
+	double warm = 0.0;
+	if (WBC) {
+		const double *pw;
+		if (lane < 21)
+			pw = wx.M + min(16 * lane, kNU * kNU - 1);
+		else if (lane < 35)
+			pw = wx.Jf + min(16 * (lane - 21), 12 * kNU - 1);
+		else if (lane < 37)
+			pw = wx.h + min(16 * (lane - 35), kNU - 1);
+		else if (lane < 39)
+			pw = wx.M + ((lane == 37) ? kNU * kNU - 1 : 0);
+		else if (lane < 41)
+			pw = wx.Jf + ((lane == 39) ? 12 * kNU - 1 : 0);
+		else
+			pw = wx.Jdu + ((lane & 1) ? 11 : 0);
+		warm = *pw;
+	}
 	if (WBC && lane < 24)
 		l.b3[lane] = wbc_rhs3(wx, a.wprm, lane);
 	if (a.out.v)
 		for (int i = lane; i < a.Ptot; i += kWave)
 			a.out.v[(size_t)inst * a.Ptot + i] = 0.0;
 	wave_sync();
+	asm volatile("" ::"v"(warm));  // the warming loads must be issued; their values are not used
 
 	HOQP_STAMP(0);
-	int pseen = 0;
 	for (int k = 0; k < a.L; ++k) {
 		int m, p;
 		if (WBC) {
@@ -2632,7 +2662,29 @@ __global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
 			p = min(max(pi, 0), a.p[k]);
 			if (m != mi || p != pi)
 				st.status |= HOQP_STATUS_BAD_EXTENT;
-			pseen += p;
+		}
+		if (GATE && a.skip_unread && !a.out.v && m == 0 && p > 0 && k >= a.last_ineq_use) {
+			// HOQP_OPT_SKIP_UNREAD_SLACK_LEVELS: nobody reads this level's rows (Q2) or slacks (v == NULL)
+			if (lane < NR && st.nskip < kReplaySteps)
+				l.xstep[st.nskip * NR + lane] = 0.0;
+			if (st.nskip < kReplaySteps)
+				++st.nskip;
+			else
+				st.replay_ok = 0;
+			if (lane == 0) {
+				const size_t o = (size_t)inst * a.L + k;
+				if (a.out.level_res)
+					a.out.level_res[o] = 0.0;
+				if (a.out.iters)
+					a.out.iters[o] = 0;
+				if (a.out.nz_levels)
+					a.out.nz_levels[o] = st.nz;
+			}
+			if (a.out.x_levels && lane < a.n)
+				a.out.x_levels[((size_t)inst * a.L + k) * a.n + lane] = (lane < n) ? l.x[lane] : 0.0;
+			st.Pout += p;
+			wave_sync();
+			continue;
 		}
 		solve_level<GATE, HARD, WBC>(a, l, st, inst, k, m, p, wx, jc);
 	}

@@ -31,6 +31,7 @@ STATUS_WORKSPACE = 0x04
 STATUS_NONFINITE = 0x08
 STATUS_BAD_EXTENT = 0x20
 NOALLOC_MAX_BATCH = 256
+OPT_SKIP_UNREAD_SLACK_LEVELS = 0x01
 
 EXPORTS = (
     "hoqp_default_config", "hoqp_create", "hoqp_destroy", "hoqp_last_error_string",
@@ -51,7 +52,7 @@ class Config(C.Structure):
     _fields_ = [("device", C.c_int), ("semantics", C.c_int), ("eps", C.c_double), ("max_iter", C.c_int),
                 ("mu", C.c_double), ("tau_max", C.c_double), ("tau_min", C.c_double),
                 ("kp_swing", C.c_double), ("kv_swing", C.c_double), ("kp_base", C.c_double),
-                ("kv_base", C.c_double), ("kv_rot", C.c_double)]
+                ("kv_base", C.c_double), ("kv_rot", C.c_double), ("options", C.c_int)]
 
 
 class QuadrupedModel(C.Structure):
