@@ -64,6 +64,28 @@ __device__ __forceinline__ double wave_sum(double v)
 	return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
 }
 
+// N wave sums at once: the same butterflies as wave_sum with the N dependency chains interleaved (a
+// single wave_sum is a chain of ~16 dependent operations; with one wave per SIMD nothing else hides it)
+template <int N>
+__device__ __forceinline__ void wave_sum_n(double (&v)[N])
+{
+#pragma unroll
+	for (int i = 0; i < N; ++i)
+		v[i] += dpp_d<0xB1>(v[i]);
+#pragma unroll
+	for (int i = 0; i < N; ++i)
+		v[i] += dpp_d<0x4E>(v[i]);
+#pragma unroll
+	for (int i = 0; i < N; ++i)
+		v[i] += dpp_d<0x141>(v[i]);
+#pragma unroll
+	for (int i = 0; i < N; ++i)
+		v[i] += dpp_d<0x140>(v[i]);
+#pragma unroll
+	for (int i = 0; i < N; ++i)
+		v[i] = (readlane_d(v[i], 0) + readlane_d(v[i], 16)) + (readlane_d(v[i], 32) + readlane_d(v[i], 48));
+}
+
 __device__ __forceinline__ double wave_max(double v)
 {
 	v = fmax(v, dpp_d<0xB1>(v));

@@ -373,7 +373,7 @@ static void fill_common(hoqp_handle *h, SolveArgs *a)
 	}
 	a->Ptot = P;
 	a->mmax = mm;
-	a->ld = a->n | 1;
+	a->ld = lds_leading_dim(a->n);
 }
 
 static int fill_args(hoqp_handle *h, const hoqp_task_batch *t, const hoqp_result_batch *out, SolveArgs *a)
@@ -428,7 +428,7 @@ extern "C" size_t hoqp_lds_bytes(int n, int num_levels, const int *m, const int 
 	}
 	a.Ptot = P;
 	a.mmax = mm;
-	a.ld = n | 1;
+	a.ld = lds_leading_dim(n);
 	a.use_bl = 1;
 	return (size_t)lds_offsets(a).total;
 }
@@ -441,8 +441,8 @@ static int launch_solve(hoqp_handle *h, SolveArgs &a, hipStream_t s, bool wbc, b
 	// profiling build: per-section cycle stamps of one launch, printed to stderr
 	unsigned long long *dbg = nullptr;
 	if (getenv("HOQP_DBG") && a.batch > 0) {
-		HIP_OK(h, hipMalloc(&dbg, sizeof(unsigned long long) * 32 * a.batch));
-		HIP_OK(h, hipMemset(dbg, 0, sizeof(unsigned long long) * 32 * a.batch));
+		HIP_OK(h, hipMalloc(&dbg, sizeof(unsigned long long) * kDbgSlots * a.batch));
+		HIP_OK(h, hipMemset(dbg, 0, sizeof(unsigned long long) * kDbgSlots * a.batch));
 	}
 	a.dbg = dbg;
 	struct Dump {
@@ -455,12 +455,12 @@ static int launch_solve(hoqp_handle *h, SolveArgs &a, hipStream_t s, bool wbc, b
 			if (!d)
 				return;
 			(void)hipStreamSynchronize(s);
-			std::vector<unsigned long long> host((size_t)32 * batch);
+			std::vector<unsigned long long> host((size_t)kDbgSlots * batch);
 			(void)hipMemcpy(host.data(), d, host.size() * 8, hipMemcpyDeviceToHost);
-			double sum[32] = {0};
+			double sum[kDbgSlots] = {0};
 			for (int i = 0; i < batch; ++i)
-				for (int j = 0; j < 32; ++j)
-					sum[j] += (double)host[(size_t)i * 32 + j];
+				for (int j = 0; j < kDbgSlots; ++j)
+					sum[j] += (double)host[(size_t)i * kDbgSlots + j];
 			static const char *nm[16] = {"init", "project", "factor", "ls/bl", "rotate", "qp.misc", "update", "tail",
 						     "eqp.load+W", "eqp.B", "eqp.ls", "eqp.Qp", "qp.mult", "qp.search", "#eqp", "#eqp.csne"};
 			double tot = 0;
@@ -476,13 +476,17 @@ static int launch_solve(hoqp_handle *h, SolveArgs &a, hipStream_t s, bool wbc, b
 			fprintf(stderr, "[hoqp profile] update parts: rows=%.0f of which issue=%.0f wait=%.0f dots=%.0f stores=%.0f\n", sum[27] / batch, sum[28] / batch, sum[29] / batch, sum[30] / batch, sum[31] / batch);
 			fprintf(stderr, "[hoqp profile] EQP rank-deficient LS: sum(nunp)=%.3f  #(nunp>4)=%.4f #(nunp>8)=%.4f #(nb>32)=%.4f per instance\n",
 				sum[23] / batch, sum[24] / batch, sum[25] / batch, sum[26] / batch);
+			if (sum[32] > 0)
+				fprintf(stderr, "[hoqp profile] reference replay: %.4f per instance; cycles per replay: project=%.0f regsolve=%.0f xr=%.0f lu=%.0f kernel=%.0f product=%.0f\n",
+					sum[32] / batch, sum[33] / sum[32], sum[34] / sum[32], sum[35] / sum[32], sum[36] / sum[32],
+					sum[37] / sum[32], sum[38] / sum[32]);
 			(void)hipFree(d);
 		}
 	} dump{h, dbg, a.batch, s};
 #else
 	a.dbg = nullptr;
 #endif
-	a.ld = a.n | 1;
+	a.ld = lds_leading_dim(a.n);
 	size_t lds = (size_t)lds_offsets(a).total;
 	if ((int)lds > h->max_lds)
 		return fail(h, -5, "LDS workspace " + std::to_string(lds) + " B exceeds the device limit");

@@ -26,6 +26,7 @@ constexpr int SROW = 36;  // row stride of the task staging buffer of the n_z ==
 			  // aligned rows); the matrix-core projection loads its operand from global memory
 constexpr int XROWS = 16; // dumped unpivoted columns (rank-deficient least squares); aliases S
 constexpr int CHUNK = 16; // task rows per projection pass (one 16 x K matrix-core operand tile)
+constexpr int kDbgSlots = 48;	  // HOQP_PROFILE builds: cycle-stamp slots per instance
 constexpr int kReplaySteps = 2;	  // inequality-only levels whose x step the reference replay can carry
 // the reference replay runs when eps / (smallest pivot)^2 of an unconstrained level exceeds this
 constexpr double kReplayTau = 3e-8;
@@ -55,6 +56,17 @@ struct SolveArgs {
 	double *qdd, *tau;  // [batch][12] outputs of the fused tail (may be null)
 	unsigned long long *dbg;  // HOQP_PROFILE builds only: [batch][16] cycle stamps per section
 };
+
+// Leading dimension (in doubles) of the row-major LDS matrices Z, G, BL, X and of the projected task rows.
+inline int lds_leading_dim(int n)
+{
+#ifdef HOQP_LD36
+	(void)n;
+	return 36;
+#else
+	return n | 1;
+#endif
+}
 
 // byte offsets of the LDS arrays (shared by host sizing and device addressing)
 struct LdsOff {
@@ -1164,7 +1176,7 @@ __device__ __forceinline__ void project_task_mfma(Src &src, int rows, int nz, co
 	do {                                                                          \
 		unsigned long long now_ = __builtin_amdgcn_s_memtime();               \
 		if (a.dbg && lane_id() == 0)                                          \
-			a.dbg[(size_t)blockIdx.x * 32 + (slot)] += now_ - st.t_last;  \
+			a.dbg[(size_t)blockIdx.x * kDbgSlots + (slot)] += now_ - st.t_last;  \
 		st.t_last = __builtin_amdgcn_s_memtime();                             \
 	} while (0)
 #else
@@ -1174,7 +1186,7 @@ __device__ __forceinline__ void project_task_mfma(Src &src, int rows, int nz, co
 #endif
 
 #ifdef HOQP_PROFILE
-#define HOQP_DBGP (a.dbg ? a.dbg + (size_t)blockIdx.x * 32 : nullptr)
+#define HOQP_DBGP (a.dbg ? a.dbg + (size_t)blockIdx.x * kDbgSlots : nullptr)
 #else
 #define HOQP_DBGP nullptr
 #endif
@@ -1292,12 +1304,12 @@ __device__ __forceinline__ double eqp_step(const SolveArgs &a, const Lds &l, Lev
 	wave_sync();
 #ifdef HOQP_PROFILE
 	if (a.dbg && lane == 0) {
-		a.dbg[(size_t)blockIdx.x * 32 + 14] += 1;           // EQP calls
-		a.dbg[(size_t)blockIdx.x * 32 + 15] += (nunp > 0);  // ... that needed the semi-normal path
-		a.dbg[(size_t)blockIdx.x * 32 + 23] += nunp;
-		a.dbg[(size_t)blockIdx.x * 32 + 24] += (nunp > 4);
-		a.dbg[(size_t)blockIdx.x * 32 + 25] += (nunp > 8);
-		a.dbg[(size_t)blockIdx.x * 32 + 26] += (nunp > 0 && k2 - k1 + nunp > 32);
+		a.dbg[(size_t)blockIdx.x * kDbgSlots + 14] += 1;           // EQP calls
+		a.dbg[(size_t)blockIdx.x * kDbgSlots + 15] += (nunp > 0);  // ... that needed the semi-normal path
+		a.dbg[(size_t)blockIdx.x * kDbgSlots + 23] += nunp;
+		a.dbg[(size_t)blockIdx.x * kDbgSlots + 24] += (nunp > 4);
+		a.dbg[(size_t)blockIdx.x * kDbgSlots + 25] += (nunp > 8);
+		a.dbg[(size_t)blockIdx.x * kDbgSlots + 26] += (nunp > 0 && k2 - k1 + nunp > 32);
 	}
 #endif
 	double q = ls_solve_reg(k1, k2, w, ncol, nunp, 0.0, ld, nullptr, l);
@@ -1405,25 +1417,52 @@ __device__ __forceinline__ int lds_fullpivlu(ldsd *M, int r, int c, ldsi *cperm)
 	const int size = min(r, c);
 	double maxpivot = 0.0;
 	int nonzero = size;
+	constexpr int EPL = 8;  // corner entries per lane: 8 * 64 >= 18 * 27 of the WBC; larger corners loop
+	// e / w for 0 <= e < 2^15, 1 <= w <= 32 without an integer division: (e + 0.5) / w is at least 0.5 / w
+	// away from an integer, far more than the rounding of the float product
+	auto idiv = [](int e, float rw) { return (int)(((float)e + 0.5f) * rw); };
 	for (int k = 0; k < size; ++k) {
+		// ---- pivot search over the corner [k, r) x [k, c), entries spread over all lanes so that the
+		//      loads of a lane are independent and in flight together ----
+		const int cw = c - k, ne = (r - k) * cw;
+		const float rcw = 1.0f / (float)cw;
 		double best = -1.0;
-		int bi = k;
-		if (lane >= k && lane < c)
-			for (int i = k; i < r; ++i) {
-				const double v = fabs(M[i * c + lane]);
-				if (v > best) {
-					best = v;
-					bi = i;
-				}
+		int bkey = 0x7fffffff;  // column-major position j * 64 + i of the lane's best entry
+		for (int e0 = 0; e0 < ne; e0 += EPL * kWave) {
+			double v[EPL];
+			int key[EPL];
+#pragma unroll
+			for (int t = 0; t < EPL; ++t) {
+				const int e = e0 + lane + kWave * t;
+				const int ec = (e < ne) ? e : 0;
+				const int qi = idiv(ec, rcw);
+				const int i = k + qi, j = k + ec - qi * cw;
+				v[t] = M[i * c + j];
+				key[t] = (e < ne) ? j * 64 + i : 0x7fffffff;
 			}
+#pragma unroll
+			for (int t = 0; t < EPL; ++t) {
+				const double av = fabs(v[t]);
+				const bool valid = key[t] != 0x7fffffff;
+				const bool take = valid && (av > best || (av == best && key[t] < bkey));
+				best = take ? av : best;
+				bkey = take ? key[t] : bkey;
+			}
+		}
 		const double mx = wave_max(best);
 		if (!(mx > 0.0)) {
 			nonzero = k;
 			break;
 		}
-		const unsigned long long bal = __ballot(best == mx);
-		const int bj = uni(__ffsll((long long)bal) - 1);
-		bi = uni(__builtin_amdgcn_readlane(bi, bj));
+		// among the lanes holding the maximum: the first entry in column-major order (one lane, usually)
+		const unsigned long long cand = __ballot(best == mx);
+		int pk;
+		if (__popcll(cand) == 1)
+			pk = __builtin_amdgcn_readlane(bkey, __ffsll((long long)cand) - 1);
+		else
+			pk = (int)wave_min((best == mx) ? (double)bkey : 1e18);
+		pk = uni(pk);
+		const int bj = pk >> 6, bi = pk & 63;
 		maxpivot = fmax(maxpivot, mx);
 		wave_sync();
 		if (bi != k && lane < c) {
@@ -1449,9 +1488,28 @@ __device__ __forceinline__ int lds_fullpivlu(ldsd *M, int r, int c, ldsi *cperm)
 		if (lane > k && lane < r)
 			M[lane * c + k] = M[lane * c + k] / piv;
 		wave_sync();
-		if (lane > k && lane < c)
-			for (int i = k + 1; i < r; ++i)
-				M[i * c + lane] = fma(-M[i * c + k], M[k * c + lane], M[i * c + lane]);
+		// ---- rank-1 update of the corner (k, r) x (k, c), again spread over all lanes ----
+		const int cw1 = c - k - 1, ne1 = (r - k - 1) * cw1;
+		const float rcw1 = 1.0f / (float)(cw1 > 0 ? cw1 : 1);
+		for (int e0 = 0; e0 < ne1; e0 += EPL * kWave) {
+			double mij[EPL], lik[EPL], ukj[EPL];
+			int adr[EPL];
+#pragma unroll
+			for (int t = 0; t < EPL; ++t) {
+				const int e = e0 + lane + kWave * t;
+				const int ec = (e < ne1) ? e : 0;
+				const int qi = idiv(ec, rcw1);
+				const int i = k + 1 + qi, j = k + 1 + ec - qi * cw1;
+				adr[t] = (e < ne1) ? i * c + j : -1;
+				mij[t] = M[i * c + j];
+				lik[t] = M[i * c + k];
+				ukj[t] = M[k * c + j];
+			}
+#pragma unroll
+			for (int t = 0; t < EPL; ++t)
+				if (adr[t] >= 0)
+					M[adr[t]] = fma(-lik[t], ukj[t], mij[t]);
+		}
 		wave_sync();
 	}
 	const double thr = maxpivot * (kEpsMach * (double)size);
@@ -1465,77 +1523,147 @@ __device__ __forceinline__ void lds_lu_kernel(const ldsd *M, int c, int rank, co
 {
 	const int lane = lane_id();
 	const int dk = c - rank;
+	// rows in pivot POSITION order first (X = U11^-1 U12 by back substitution, one kernel column per
+	// lane, the loads of a row's terms in flight together), scattered to the original rows at the end
 	if (lane < dk) {
-		for (int q = 0; q < dk; ++q)
-			K[cperm[rank + q] * dk + lane] = (q == lane) ? 1.0 : 0.0;
 		for (int i = rank - 1; i >= 0; --i) {
-			double s = M[i * c + rank + lane];
-			for (int j = i + 1; j < rank; ++j)
-				s = fma(M[i * c + j], K[cperm[j] * dk + lane], s);  // K holds -X
-			K[cperm[i] * dk + lane] = -(s / M[i * c + i]);
+			double sacc = M[i * c + rank + lane];
+			for (int j0 = i + 1; j0 < rank; j0 += 4) {
+				double u[4], xv[4];
+#pragma unroll
+				for (int t = 0; t < 4; ++t) {
+					const int j = (j0 + t < rank) ? j0 + t : i + 1;
+					u[t] = M[i * c + j];
+					xv[t] = K[j * dk + lane];
+				}
+#pragma unroll
+				for (int t = 0; t < 4; ++t)
+					sacc = (j0 + t < rank) ? fma(-u[t], xv[t], sacc) : sacc;
+			}
+			K[i * dk + lane] = sacc / M[i * c + i];
 		}
+	}
+	wave_sync();
+	// K currently holds X in rows [0, rank); build the kernel in place: row cperm[i] = -X_i, row of the
+	// q-th free column = e_q.  Rows are permuted, so go through registers: every lane reads its entries
+	// of X first, then all lanes write.
+	{
+		const int total = c * dk;  // entries of the final K
+		constexpr int PASS = 16;   // 16 * 64 >= 30 * 24
+		double val[PASS];
+		int dst[PASS];
+#pragma unroll
+		for (int t = 0; t < PASS; ++t) {
+			const int e = lane + kWave * t;
+			const bool on = e < total;
+			const int ec = on ? e : 0;
+			const int pos = (int)(((float)ec + 0.5f) * (1.0f / (float)dk)), q = ec - pos * dk;  // position, kernel column
+			const int orig = cperm[pos < c ? pos : 0];
+			double v;
+			if (pos < rank)
+				v = -K[pos * dk + q];
+			else
+				v = (pos - rank == q) ? 1.0 : 0.0;
+			val[t] = v;
+			dst[t] = on ? orig * dk + q : -1;
+		}
+		wave_sync();
+#pragma unroll
+		for (int t = 0; t < PASS; ++t)
+			if (dst[t] >= 0)
+				K[dst[t]] = val[t];
 	}
 	wave_sync();
 }
 
+constexpr int kRegC = 12;  // columns of the stacked system held in registers (WBC: <= 12)
+// Householder steps K.. of the lane-per-row QR (recursion = full unrolling with the step index a
+// compile-time constant, so that the dot products of one step are reduced together, wave_sum_n)
+template <int K>
+__device__ __forceinline__ void reg_qr_steps(double (&w)[kRegC + 1], int C, int R)
+{
+	if constexpr (K < kRegC) {
+		if (K < C) {
+			const int lane = lane_id();
+			const bool on = lane >= K && lane < R;
+			double v = on ? w[K] : 0.0;
+			const double alpha = readlane_d(v, K);
+			const double nrm = sqrt(wave_sum(v * v));
+			if (nrm > 0.0) {
+				const double beta = (alpha >= 0.0) ? -nrm : nrm;
+				v = (lane == K) ? alpha - beta : v;
+				const double tk = 1.0 / (nrm * (nrm + fabs(alpha)));
+				double d[kRegC - K];  // columns K+1 .. kRegC-1 and the right-hand side (slot kRegC)
+#pragma unroll
+				for (int j = K + 1; j <= kRegC; ++j)
+					d[j - K - 1] = v * w[j];
+				wave_sum_n(d);
+#pragma unroll
+				for (int j = K + 1; j <= kRegC; ++j)
+					w[j] = fma(-d[j - K - 1] * tk, v, w[j]);
+				w[K] = (lane == K) ? beta : w[K];
+			}
+			reg_qr_steps<K + 1>(w, C, R);
+		}
+	}
+}
+
 // zout (nz) = argmin |M z - r|^2 + eps |z|^2, M (m x nz, stride nz) and r in LDS, by Householder QR
-// of the stacked system, one row per lane: m > nz:  [M; sqrt(eps) I] z = [r; 0];  m <= nz (dual):
-// z = M' w with [M'; sqrt(eps) I] w = [0; r / sqrt(eps)].  W: (m + nz) x (min(m, nz) + 1) doubles.
-__device__ __forceinline__ void lds_reg_solve(const ldsd *M, const ldsd *r, int m, int nz, double eps, ldsd *W, ldsd *wv,
-					      ldsd *zout)
+// of the stacked system, one row per lane, the row held in registers (C = min(m, nz) <= kRegC columns
+// plus the right-hand side; the column loops are unrolled over kRegC with wave-uniform guards):
+//   m > nz:  [M; sqrt(eps) I] z = [r; 0];   m <= nz (dual):  z = M' w with [M'; sqrt(eps) I] w = [0; r / sqrt(eps)].
+__device__ __forceinline__ void lds_reg_solve(const ldsd *M, const ldsd *r, int m, int nz, double eps, ldsd *wv, ldsd *zout)
 {
 	const int lane = lane_id();
 	const bool dual = m <= nz;
-	const int C = dual ? m : nz, R = m + nz, ldw = C + 1;
+	const int C = dual ? m : nz, R = m + nz;
 	const double se = sqrt(eps);
-	if (lane < R)
-		for (int j = 0; j <= C; ++j) {
-			double v;
+	double w[kRegC + 1];
+	// the lane's row: all loads first (clamped addresses), then the selects
+	{
+		double ld_[kRegC + 1];
+#pragma unroll
+		for (int j = 0; j <= kRegC; ++j) {
+			const int jc = (j < C) ? j : 0;
+			const ldsd *src;
+			if (dual)
+				src = (j < C) ? M + jc * nz + (lane < nz ? lane : 0) : r + ((lane >= nz && lane < R) ? lane - nz : 0);
+			else
+				src = (j < C) ? M + (lane < m ? lane : 0) * nz + jc : r + (lane < m ? lane : 0);
+			ld_[j] = *src;
+		}
+#pragma unroll
+		for (int j = 0; j <= kRegC; ++j) {
+			double v = 0.0;
+			const int jj = (j == kRegC) ? C : j;  // slot kRegC holds the right-hand side
+			(void)jj;
 			if (dual) {
-				if (lane < nz)
-					v = (j < C) ? M[j * nz + lane] : 0.0;
+				if (j < kRegC)
+					v = (j < C) ? ((lane < nz) ? ld_[j] : ((lane - nz == j && lane < R) ? se : 0.0)) : 0.0;
 				else
-					v = (j < C) ? ((lane - nz == j) ? se : 0.0) : r[lane - nz] / se;
+					v = (lane >= nz && lane < R) ? ld_[kRegC] / se : 0.0;
 			} else {
-				if (lane < m)
-					v = (j < C) ? M[lane * nz + j] : r[lane];
+				if (j < kRegC)
+					v = (j < C) ? ((lane < m) ? ld_[j] : ((lane - m == j && lane < R) ? se : 0.0)) : 0.0;
 				else
-					v = (j < C) ? ((lane - m == j) ? se : 0.0) : 0.0;
+					v = (lane < m) ? ld_[kRegC] : 0.0;
 			}
-			W[lane * ldw + j] = v;
+			w[j] = v;
 		}
-	wave_sync();
-	for (int k = 0; k < C; ++k) {
-		const bool on = lane >= k && lane < R;
-		double v = on ? W[(on ? lane : 0) * ldw + k] : 0.0;
-		const double alpha = readlane_d(v, k);
-		const double nrm = sqrt(wave_sum(v * v));
-		if (!(nrm > 0.0))
+	}
+	reg_qr_steps<0>(w, C, R);
+	// back substitution: lane i holds row i of R and the transformed right-hand side
+	double acc = w[kRegC];
+#pragma unroll
+	for (int i = kRegC - 1; i >= 0; --i) {
+		if (i >= C)
 			continue;
-		const double beta = (alpha >= 0.0) ? -nrm : nrm;
-		if (lane == k)
-			v = alpha - beta;
-		const double tk = 1.0 / (nrm * (nrm + fabs(alpha)));
-		for (int j = k + 1; j <= C; ++j) {
-			const double e = on ? W[(on ? lane : 0) * ldw + j] : 0.0;
-			const double d = wave_sum(v * e) * tk;
-			if (on)
-				W[lane * ldw + j] = fma(-d, v, e);
-		}
-		if (lane == k)
-			W[k * ldw + k] = beta;
-		wave_sync();
-	}
-	for (int i = C - 1; i >= 0; --i) {
-		double sacc = W[i * ldw + C];
-		for (int j = i + 1; j < C; ++j)
-			sacc = fma(-W[i * ldw + j], wv[j], sacc);
-		const double wi = sacc / W[i * ldw + i];
-		wave_sync();
+		const double si = readlane_d(acc / w[i], i);
+		acc = fma(-w[i], si, acc);
 		if (lane == 0)
-			wv[i] = wi;
-		wave_sync();
+			wv[i] = si;
 	}
+	wave_sync();
 	if (lane < nz) {
 		double z = 0.0;
 		if (dual) {
@@ -1557,14 +1685,29 @@ __device__ __forceinline__ bool ref_replay(const SolveArgs &a, const Lds &l, int
 	const int lane = lane_id();
 	const int Gcap = (a.Ptot ? a.Ptot : 1) * a.ld;
 	const int tvcap = (LDV * a.n > a.ld * a.mmax) ? LDV * a.n : a.ld * a.mmax;
-	const int Scap = (CHUNK * SROW > XROWS * a.ld) ? CHUNK * SROW : XROWS * a.ld;
 	ldsd *xr = l.tmp, *zv = l.tmp + NR, *wv = l.tau;
 #ifdef HOQP_REPLAY_DEBUG
 #define RDBG(...) do { if (lane == 0) printf(__VA_ARGS__); } while (0)
 #else
 #define RDBG(...) do { } while (0)
 #endif
-	RDBG("[replay] inst %d k %d n %d nz_entry %d Gcap %d tvcap %d Scap %d\n", inst, k, n, nz_entry, Gcap, tvcap, Scap);
+	RDBG("[replay] inst %d k %d n %d nz_entry %d Gcap %d tvcap %d\n", inst, k, n, nz_entry, Gcap, tvcap);
+#ifdef HOQP_PROFILE
+	unsigned long long rt_ = __builtin_amdgcn_s_memtime();
+#define RSTAMP(slot)                                                                          \
+	do {                                                                                  \
+		const unsigned long long n_ = __builtin_amdgcn_s_memtime();                   \
+		if (a.dbg && lane == 0)                                                       \
+			a.dbg[(size_t)blockIdx.x * kDbgSlots + (slot)] += n_ - rt_;           \
+		rt_ = __builtin_amdgcn_s_memtime();                                           \
+	} while (0)
+	if (a.dbg && lane == 0)
+		a.dbg[(size_t)blockIdx.x * kDbgSlots + 32] += 1;
+#else
+#define RSTAMP(slot) \
+	do {         \
+	} while (0)
+#endif
 	if (n >= NR)
 		return false;
 	wave_sync();
@@ -1601,7 +1744,7 @@ __device__ __forceinline__ bool ref_replay(const SolveArgs &a, const Lds &l, int
 		const int cmin = min(mj, nzr);
 		RDBG("[replay]  level %d m %d nzr %d\n", j, mj, nzr);
 		// TV: M (mj x nzr) and, for j < k, the kernel matrix (nzr x (nzr - rank), rank = mj unless deficient)
-		if (mj * nzr + (j < k ? nzr * (nzr - cmin) : 0) > tvcap || (mj + nzr) * (cmin + 1) > Scap || mj + nzr > kWave)
+		if (mj * nzr + (j < k ? nzr * (nzr - cmin) : 0) > tvcap || cmin > kRegC || mj + nzr > kWave)
 			return false;
 		{
 			// M = A_j Zr -> TV (stride nzr),  r = b_j - A_j xr -> l.rhs
@@ -1627,7 +1770,9 @@ __device__ __forceinline__ bool ref_replay(const SolveArgs &a, const Lds &l, int
 				project_task_mfma(src, mj, nzr, bm, dst, l);
 			}
 		}
-		lds_reg_solve(l.TV, l.rhs, mj, nzr, a.eps, l.S, wv, zv);
+		RSTAMP(33);
+		lds_reg_solve(l.TV, l.rhs, mj, nzr, a.eps, wv, zv);
+		RSTAMP(34);
 		if (j == k) {  // |A_k x_k - b_k|^2 at the regularised optimum
 			double ri = 0.0;
 			if (lane < mj) {
@@ -1642,14 +1787,26 @@ __device__ __forceinline__ bool ref_replay(const SolveArgs &a, const Lds &l, int
 			if (zident) {
 				sx += zv[lane];
 			} else {
-				for (int q = 0; q < nzr; ++q)
-					sx = fma(Zr[lane * nzr + q], zv[q], sx);
+				for (int q0 = 0; q0 < nzr; q0 += 8) {
+					double za[8], zb[8];
+#pragma unroll
+					for (int u = 0; u < 8; ++u) {
+						const int q = (q0 + u < nzr) ? q0 + u : 0;
+						za[u] = Zr[lane * nzr + q];
+						zb[u] = zv[q];
+					}
+#pragma unroll
+					for (int u = 0; u < 8; ++u)
+						sx = (q0 + u < nzr) ? fma(za[u], zb[u], sx) : sx;
+				}
 			}
 			xr[lane] = sx;
 		}
 		wave_sync();
+		RSTAMP(35);
 		if (j < k) {
 			const int rank = uni(lds_fullpivlu(l.TV, mj, nzr, l.colpos));
+			RSTAMP(36);
 			const int dk = nzr - rank;
 			RDBG("[replay]  level %d rank %d\n", j, rank);
 			if (dk == 0) {
@@ -1660,26 +1817,39 @@ __device__ __forceinline__ bool ref_replay(const SolveArgs &a, const Lds &l, int
 				return false;
 			ldsd *K = l.TV + mj * nzr;
 			lds_lu_kernel(l.TV, nzr, rank, l.colpos, K);
+			RSTAMP(37);
 			const int newoff = (zident || zoff != 0) ? 0 : n * nzr;
 			if (newoff + n * dk > Gcap || (!zident && newoff == 0 && n * dk > zoff))
 				return false;
 			ldsd *Zn = l.G + newoff;
-			// Zn (n x dk) = Zr K; two lanes per row
-			{
-				const int row = lane >> 1, h = lane & 1;
-				if (row < n)
-					for (int q = h; q < dk; q += 2) {
-						double sacc = 0.0;
-						if (zident) {
-							sacc = K[row * dk + q];
-						} else {
-							for (int t = 0; t < nzr; ++t)
-								sacc = fma(Zr[row * nzr + t], K[t * dk + q], sacc);
+			// Zn (n x dk) = Zr K: one output entry per lane and pass, the dot product in blocks of
+			// eight terms whose loads are in flight together (same summation order as a plain loop)
+			for (int e0 = 0; e0 < n * dk; e0 += kWave) {
+				const int e = e0 + lane;
+				const bool on = e < n * dk;
+				const int row = on ? e / dk : 0, q = on ? e - (e / dk) * dk : 0;
+				double sacc = 0.0;
+				if (zident) {
+					sacc = K[row * dk + q];
+				} else {
+					for (int t0 = 0; t0 < nzr; t0 += 8) {
+						double za[8], kb[8];
+#pragma unroll
+						for (int u = 0; u < 8; ++u) {
+							const int t = (t0 + u < nzr) ? t0 + u : 0;
+							za[u] = Zr[row * nzr + t];
+							kb[u] = K[t * dk + q];
 						}
-						Zn[row * dk + q] = sacc;
+#pragma unroll
+						for (int u = 0; u < 8; ++u)
+							sacc = (t0 + u < nzr) ? fma(za[u], kb[u], sacc) : sacc;
 					}
+				}
+				if (on)
+					Zn[e] = sacc;
 			}
 			wave_sync();
+			RSTAMP(38);
 			Zr = Zn;
 			zident = false;
 			zoff = newoff;

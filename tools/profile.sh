@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/rocprof
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp
-BENCH="python3 $ROOT/bench.py --no-cpu-baseline --steps 20 --warmup 3"
+BENCH="python3 $ROOT/bench.py --no-cpu-baseline --steps 20 --warmup 3 --latency-batches 2"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
 echo trace done
 pmc() { name=$1; shift; timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- $BENCH > $OUT/$name.log 2>&1; echo $name done; }
@@ -20,8 +20,8 @@ cd $ROOT
 python3 tools/profile_summarize.py gpurun_out/rocprof gpurun_out/rocprof/summary
 # full bench line (with the CPU baseline) and the per-section cycle profile of the profiling build
 timeout -k 10 400 python3 bench.py > gpurun_out/rocprof/bench_full.json
-HOQP_DBG=1 HOQP_LIB=$PWD/quadruped_locomotion_amd/libhoqp_hip_prof.so timeout -k 10 200 python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 2> gpurun_out/rocprof/sections_reference.txt > /dev/null
-HOQP_DBG=1 HOQP_LIB=$PWD/quadruped_locomotion_amd/libhoqp_hip_prof.so timeout -k 10 200 python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 --mode paper 2> gpurun_out/rocprof/sections_paper.txt > /dev/null
+HOQP_DBG=1 HOQP_LIB=$PWD/quadruped_locomotion_amd/libhoqp_hip_prof.so timeout -k 10 200 python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 --latency-batches 2 2> gpurun_out/rocprof/sections_reference.txt > /dev/null
+HOQP_DBG=1 HOQP_LIB=$PWD/quadruped_locomotion_amd/libhoqp_hip_prof.so timeout -k 10 200 python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 --latency-batches 2 --mode paper 2> gpurun_out/rocprof/sections_paper.txt > /dev/null
 timeout -k 10 200 python3 bench.py --no-cpu-baseline --mode paper > gpurun_out/rocprof/bench_paper.json
 timeout -k 10 200 python3 bench.py --no-cpu-baseline --contact trot > gpurun_out/rocprof/bench_trot.json
 echo all done
