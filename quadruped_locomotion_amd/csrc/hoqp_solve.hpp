@@ -612,6 +612,26 @@ __device__ __forceinline__ double gauss_jordan8(double mval, double gval)
 	return gval;
 }
 
+// The same with the smallest pivot reported (conditioning guard of the normal-equations shortcut).
+__device__ __forceinline__ double gauss_jordan8_piv(double mval, double gval, double *minpiv)
+{
+	const int lane = lane_id(), i = lane >> 3, j = lane & 7;
+	double mp = 1e300;
+#pragma unroll
+	for (int k = 0; k < 8; ++k) {
+		const double pv = readlane_d(mval, 9 * k);
+		mp = fmin(mp, pv);
+		const double rpv = fast_rcp(pv);
+		const double mik = __shfl(mval, i * 8 + k);
+		const double mkj = __shfl(mval, k * 8 + j) * rpv;
+		const double gk = readlane_d(gval, 8 * k) * rpv;
+		mval = (i == k) ? mkj : fma(-mik, mkj, mval);
+		gval = (i == k) ? gk : fma(-mik, gk, gval);
+	}
+	*minpiv = mp;
+	return gval;
+}
+
 // ---------------------------------------------------------------------------
 // Least squares on a finished factorization.  Pivot positions [k1, k2) hold the factor R_B
 // (rb = k2 - k1 rows) of the "B" columns [qB0, qB1); the right-hand side is in l.rhs[column],
@@ -1984,7 +2004,60 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 		const double r = sel(lane < m, l.rhs[lane]);
 		level_res2 = wave_sum(r * r);
 	}
-	if (factorA && tall) {
+	bool ne_done = false;
+	if (factorA && tall && !consider && nz <= 8) {
+		// ---- 2n. a tall level with at most 8 free coordinates and nothing to respect (the force
+		//          level of the WBC: 12 x 6): the normal equations ((AZ)'AZ + eps I) y = (AZ)'r -- in
+		//          an orthonormal basis literally the reference's system (ho_qp_problem.cpp:238-252) --
+		//          by an 8 x 8 Gauss-Jordan, one matrix entry per lane, instead of n_z Householder
+		//          steps.  Squaring the condition number is harmless while it is small: accepted only if
+		//          the smallest pivot is above 1e-4 of the largest diagonal entry (kappa(AZ) < 100).
+		const int gi = lane >> 3, gj = lane & 7;
+		const int ci = gi < nz ? gi : 0, cj = gj < nz ? gj : 0;
+		double g0 = 0.0, c0 = 0.0;
+		for (int r0 = 0; r0 < m; r0 += 4) {
+			double ai[4], aj[4], rr[4];
+#pragma unroll
+			for (int u = 0; u < 4; ++u) {
+				const int r = (r0 + u < m) ? r0 + u : 0;
+				ai[u] = l.TV[r * ld + ci];
+				aj[u] = l.TV[r * ld + cj];
+				rr[u] = l.rhs[r];
+			}
+#pragma unroll
+			for (int u = 0; u < 4; ++u) {
+				const bool on = r0 + u < m;
+				g0 = on ? fma(ai[u], aj[u], g0) : g0;
+				c0 = on ? fma(ai[u], rr[u], c0) : c0;
+			}
+		}
+		const bool inb = gi < nz && gj < nz;
+		const double dmax = wave_max((inb && gi == gj) ? g0 : 0.0);
+		const double mval = inb ? g0 + ((gi == gj) ? a.eps : 0.0) : ((gi == gj) ? 1.0 : 0.0);
+		const double gval = (gi < nz) ? c0 : 0.0;
+		double minpiv;
+		const double av = gauss_jordan8_piv(mval, gval, &minpiv);
+		if (minpiv > 1e-4 * dmax && dmax > 0.0) {
+			ne_done = true;
+			rank = nz;
+			yi = sel(lane < nz, __shfl(av, (8 * lane) & (kWave - 1)));
+			// residual of the level at its optimum
+			const int rc = lane < m ? lane : 0;
+			double tv[8];
+#pragma unroll
+			for (int i = 0; i < 8; ++i)
+				tv[i] = l.TV[rc * ld + (i < nz ? i : 0)];
+			double res = l.rhs[rc];
+#pragma unroll
+			for (int i = 0; i < 8; ++i)
+				res = (i < nz) ? fma(-tv[i], readlane_d(av, 8 * i), res) : res;
+			level_res2 = wave_sum(lane < m ? res * res : 0.0);
+			dmin_level = sqrt(minpiv);
+			have_y0 = true;
+			HOQP_STAMP(2);
+		}
+	}
+	if (factorA && tall && !ne_done) {
 		double x[NSP][NT];
 		int pos[NSP];
 		l.colpos[lane] = -1;
