@@ -118,6 +118,7 @@ __host__ __device__ inline LdsOff lds_offsets(const SolveArgs &a)
 struct Lds {
 	ldsd *Z, *x, *G, *g, *vs, *s, *c, *TV, *S, *BL, *r0, *rho, *a0, *tau, *rdiag, *rhs, *X, *tmp, *dump, *b3, *xstep;
 	ldsi *pivlane, *W, *xlane, *colpos, *vlist;
+	unsigned long long *dbgp;  // HOQP_PROFILE builds: this instance's cycle-stamp slots (else null)
 };
 
 __device__ __forceinline__ Lds lds_bind(const SolveArgs &a, HOQP_LDS char *base)
@@ -150,6 +151,11 @@ __device__ __forceinline__ Lds lds_bind(const SolveArgs &a, HOQP_LDS char *base)
 	l.xlane = (ldsi *)(base + o.xlane);
 	l.colpos = (ldsi *)(base + o.colpos);
 	l.vlist = (ldsi *)(base + o.vlist);
+#ifdef HOQP_PROFILE
+	l.dbgp = a.dbg ? a.dbg + (size_t)blockIdx.x * kDbgSlots : nullptr;
+#else
+	l.dbgp = nullptr;
+#endif
 	return l;
 }
 
@@ -1142,6 +1148,9 @@ struct WbcLevelSrc {
 	}
 };
 
+#ifdef HOQP_PROFILE
+#define dbgp_proj (l.dbgp)
+#endif
 template <typename Src>
 __device__ __forceinline__ void project_task_mfma(Src &src, int rows, int nz, const double (&bm)[NR / 4][2],
 						  const ProjDst dstm, const Lds &l)
@@ -1149,13 +1158,20 @@ __device__ __forceinline__ void project_task_mfma(Src &src, int rows, int nz, co
 	const int lane = lane_id();
 	const int j16 = lane & 15, q4 = lane >> 4;
 	const bool two = nz + 1 > 16;  // second block of 16 output columns needed
+#ifdef HOQP_PROFILE
+	unsigned long long pt[4] = {0, 0, 0, 0};
+	unsigned long long t0_ = __builtin_amdgcn_s_memtime();
+#endif
 	src.fetch(0, rows);
+	PF_T(0);
 	for (int r0 = 0; r0 < rows; r0 += CHUNK) {
 		const int nr = min(CHUNK, rows - r0);
 		double av[NR / 4], rvr[4];
 		src.take(av, rvr);
+		PF_T(1);
 		if (r0 + CHUNK < rows)
 			src.fetch(r0 + CHUNK, rows);
+		PF_T(0);
 		d4v acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
 		if (two) {
 #pragma unroll
@@ -1187,8 +1203,14 @@ __device__ __forceinline__ void project_task_mfma(Src &src, int rows, int nz, co
 				*dst = isX ? rvr[r] - v : v;
 			}
 		}
+		PF_T(2);
 	}
 	wave_sync();
+#ifdef HOQP_PROFILE
+	if (dbgp_proj && lane == 0)
+		for (int i = 0; i < 3; ++i)
+			dbgp_proj[39 + i] += pt[i];
+#endif
 }
 
 #ifdef HOQP_PROFILE
@@ -1934,6 +1956,9 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 			// ConstructForceMinimizationTask: A = [0 I], b = 0, so A Z is rows 18.. of Z and A x the
 			// contact forces -- copied, not multiplied (the products are exact either way)
 			if (m > 0 && doA) {
+#ifdef HOQP_PROFILE
+				const unsigned long long tb0_ = __builtin_amdgcn_s_memtime();
+#endif
 				for (int idx = lane; idx < m * nz; idx += kWave) {
 					const int r = idx / nz, j = idx - r * nz;
 					l.TV[r * ld + j] = l.Z[(kNU + r) * ld + j];
@@ -1941,10 +1966,21 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 				if (lane < m)
 					l.rhs[lane] = 0.0 - l.x[kNU + lane];
 				wave_sync();
+#ifdef HOQP_PROFILE
+				if (l.dbgp && lane == 0)
+					l.dbgp[43] += __builtin_amdgcn_s_memtime() - tb0_;
+#endif
 			}
 		} else if (WBC) {  // fused entry (n <= 30: always the matrix-core path)
 			double bm[NR / 4][2];
+#ifdef HOQP_PROFILE
+			const unsigned long long tb0_ = __builtin_amdgcn_s_memtime();
+#endif
 			load_bm(bm, n, nz, ld, l);
+#ifdef HOQP_PROFILE
+			if (l.dbgp && lane == 0)
+				l.dbgp[42] += __builtin_amdgcn_s_memtime() - tb0_;
+#endif
 			if (k == 1) {
 				if (p > 0 && doD) {
 					WbcLevelSrc<1> src(wx, a.wprm, l, jc);
@@ -1996,6 +2032,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 					     nstore, n, nz, ld, zc, false, P, l);
 		}
 	};
+	HOQP_STAMP(44);
 	project(true, true);
 	HOQP_STAMP(1);
 	const bool factorA = m > 0 && nz > 0;
@@ -2808,6 +2845,9 @@ __device__ __forceinline__ void wbc_tail(const SolveArgs &a, const Lds &l, const
 #endif  // __HIP_DEVICE_COMPILE__
 
 template <bool GATE, bool HARD, bool WBC>
+#ifdef HOQP_WAVES_PER_EU
+__attribute__((amdgpu_waves_per_eu(HOQP_WAVES_PER_EU, HOQP_WAVES_PER_EU)))
+#endif
 __global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
 {
 #ifdef __HIP_DEVICE_COMPILE__

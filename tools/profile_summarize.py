@@ -28,3 +28,17 @@ for name in ("fetch", "write", "sq1", "sq2", "sqc"):
                 pmc.setdefault(k, {})[c] = {"mean_per_launch": sum(v) / len(v), "launches": len(v)}
 json.dump(pmc, open(out + "_pmc.json", "w"), indent=1, sort_keys=True)
 print(json.dumps({k: {c: round(d["mean_per_launch"], 1) for c, d in v.items()} for k, v in pmc.items()}, indent=1))
+
+# HBM traffic of the solve kernel per launch, in the form bench.py reads (profiles/rNN_pmc_traffic.json)
+for k, cs in pmc.items():
+    if "hoqp_solve_kernel" in k and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+        fk, wk = cs["FETCH_SIZE"]["mean_per_launch"], cs["WRITE_SIZE"]["mean_per_launch"]
+        json.dump({
+            "kernel": k, "batch": 4096, "semantics": "reference", "contact": "stance",
+            "fetch_bytes_per_launch": fk * 1024.0, "write_bytes_per_launch": wk * 1024.0,
+            "fetch_size_kib": fk, "write_size_kib": wk,
+            "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate runs of `bench.py --no-cpu-baseline "
+                      "--steps 20 --warmup 3 --latency-batches 2`, tools/profile.sh), mean of the last 20 launches; KiB -> "
+                      "bytes; the gfx950 x2 correction of FETCH_SIZE is NOT applied: it is calibrated for 16-B-per-lane "
+                      "streaming reads, this kernel reads 8 B per lane (uncalibrated width)",
+        }, open(out + "_pmc_traffic.json", "w"), indent=1)
