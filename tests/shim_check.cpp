@@ -129,7 +129,7 @@ int main(int argc, char **argv)
 				ctl2.CalcJointCmd(q, u);
 				us2[i] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
 			}
-			// the reference's own call pattern on the task API: five HoQpProblem constructors, one GetSolution
+			// the reference's own call pattern on the task API: a chain of HoQpProblem constructors, one GetSolution
 			hoqp_config cur = hoqp::default_config();
 			std::vector<TaskDefinition> tk(3);
 			tk[0].A = MatrixXd::Identity(6, 30);
