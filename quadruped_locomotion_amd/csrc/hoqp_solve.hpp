@@ -997,12 +997,13 @@ typedef double d4v __attribute__((ext_vector_type(4)));
 // B operand [Zm | xv] from any LDS matrix Zm (n x nz, leading dimension ldz) and vector xv; `ident`:
 // Zm is not read and stands for the identity.  (An explicit flag, never a null test: the solver's Z
 // sits at LDS offset 0, and offset 0 is what a null test of an LDS pointer compares with.)
+template <int NKB = NR / 4>
 __device__ __forceinline__ void load_bm_from(double (&bm)[NR / 4][2], int n, int nz, int ldz, const ldsd *Zm, const ldsd *xv,
 					     bool ident)
 {
 	const int lane = lane_id(), j16 = lane & 15, q4 = lane >> 4;
 #pragma unroll
-	for (int kb = 0; kb < NR / 4; ++kb) {
+	for (int kb = 0; kb < NKB; ++kb) {
 		const int k = 4 * kb + q4;
 		const int kc = (k < n) ? k : 0;
 #pragma unroll
@@ -1013,12 +1014,12 @@ __device__ __forceinline__ void load_bm_from(double (&bm)[NR / 4][2], int n, int
 		}
 	}
 #pragma unroll
-	for (int kb = 0; kb < NR / 4; ++kb) {
+	for (int kb = 0; kb < NKB; ++kb) {
 		pin(bm[kb][0]);
 		pin(bm[kb][1]);
 	}
 #pragma unroll
-	for (int kb = 0; kb < NR / 4; ++kb) {
+	for (int kb = 0; kb < NKB; ++kb) {
 		const int k = 4 * kb + q4;
 #pragma unroll
 		for (int cb = 0; cb < 2; ++cb) {
@@ -1031,9 +1032,10 @@ __device__ __forceinline__ void load_bm_from(double (&bm)[NR / 4][2], int n, int
 	}
 }
 
+template <int NKB = NR / 4>
 __device__ __forceinline__ void load_bm(double (&bm)[NR / 4][2], int n, int nz, int ld, const Lds &l)
 {
-	load_bm_from(bm, n, nz, ld, l.Z, l.x, false);
+	load_bm_from<NKB>(bm, n, nz, ld, l.Z, l.x, false);
 }
 
 // destination of a projection: rows of (A Z) to M[row * ldm + j], right-hand sides to rhs[row]
@@ -1051,6 +1053,7 @@ struct ProjDst {
 // TaskRowsSrc: the rows of a stored task block (generic entry), each lane loading its own entries
 // straight from global memory (16 rows x 32 contiguous bytes per load instruction).
 struct TaskRowsSrc {
+	static constexpr int NKB = NR / 4;
 	const double *__restrict__ rows_g;
 	const double *__restrict__ rhs_g;
 	int nstore, n;
@@ -1092,15 +1095,17 @@ struct TaskRowsSrc {
 	}
 };
 
-// WbcLevelSrc: level LEVEL of the WBC hierarchy generated from the dynamics terms (fused entry).
+// WbcEntrySrc: level LEVEL of the WBC hierarchy through the general generator wbc_entry<LEVEL> (any level,
+// any basis: used by the reference replay; the fast path has cheaper special forms, below).
 template <int LEVEL>
-struct WbcLevelSrc {
+struct WbcEntrySrc {
+	static constexpr int NKB = NR / 4;
 	const WbcCtx &x;
 	const WbcPrm &prm;
 	const Lds &l;
 	const int (&jc)[NR / 4];  // wbc_jcoff of this lane's columns
 	double lv[NR / 4], sc[NR / 4], ad[NR / 4], rl[4], rs[4], ra[4];
-	__device__ __forceinline__ WbcLevelSrc(const WbcCtx &x_, const WbcPrm &prm_, const Lds &l_, const int (&jc_)[NR / 4])
+	__device__ __forceinline__ WbcEntrySrc(const WbcCtx &x_, const WbcPrm &prm_, const Lds &l_, const int (&jc_)[NR / 4])
 		: x(x_), prm(prm_), l(l_), jc(jc_)
 	{
 	}
@@ -1148,6 +1153,74 @@ struct WbcLevelSrc {
 	}
 };
 
+// WbcLevelSrc: the equality blocks of levels 2 and 3 of the WBC hierarchy generated from the dynamics terms
+// (fused entry).  Every row of these blocks is a row of J_foot or J_b (or a unit row) padded with zeros
+// beyond column 17, so a lane needs one row address per chunk and loads its entries at fixed offsets;
+// only the first five blocks of four columns can be non-zero (NKB = 5: the other three take no part in
+// the product).  Same values as wbc_entry<LEVEL> / wbc_rhs_entry<LEVEL> of wbc_tasks.hpp, which remain
+// the definition (tests/test_gpu_fused.py compares the two).  Levels 0, 1 and 4 do not come through here.
+constexpr int kWbcKB = 5;
+template <int LEVEL>
+struct WbcLevelSrc {
+	static constexpr int NKB = kWbcKB;
+	const WbcCtx &x;
+	const Lds &l;
+	double lv[NR / 4], rl[4];
+	int rb;	 // level 3 without J_b: the unit row's column (-1: a Jacobian row)
+	__device__ __forceinline__ WbcLevelSrc(const WbcCtx &x_, const Lds &l_) : x(x_), l(l_), rb(-1) {}
+	__device__ __forceinline__ void fetch(int r0, int rows)
+	{
+		const int lane = lane_id(), j16 = lane & 15, q4 = lane >> 4;
+		const int nr = min(CHUNK, rows - r0);
+		const int r = r0 + (j16 < nr ? j16 : 0);
+		const double *row;
+		if (LEVEL == 2) {
+			row = x.Jf + wbc_crow(x, r) * kNU;  // ConstructNoContactMotionTask: A = [J_c 0]
+		} else {
+			// base position rows (J_b rows 3..5), base rotation rows (0..2), swing feet
+			const int br = (r < 3) ? 3 + r : r - 3;
+			const double *jb = x.Jb ? x.Jb + (r < 6 ? br : 0) * kNU : x.Jf;
+			const double *js = x.Jf + wbc_srow(x, r < 6 ? 0 : r - 6) * kNU;
+			row = (r < 6) ? jb : js;
+			rb = (r < 6 && !x.Jb) ? br : -1;
+		}
+#pragma unroll
+		for (int kb = 0; kb < NKB; ++kb) {
+			const int c = 4 * kb + q4;
+			lv[kb] = row[(kb < 4 || c < kNU) ? c : 0];
+		}
+#pragma unroll
+		for (int rr = 0; rr < 4; ++rr) {
+			const int ri = r0 + (q4 + 4 * rr < nr ? q4 + 4 * rr : 0);
+			if (LEVEL == 3)
+				rl[rr] = l.b3[ri];
+			else
+				rl[rr] = x.Jdu[wbc_crow(x, ri)];  // b = -J_c_dot u
+		}
+	}
+	__device__ __forceinline__ void take(double (&av)[NR / 4], double (&rvr)[4])
+	{
+		const int q4 = lane_id() >> 4;
+#pragma unroll
+		for (int kb = 0; kb < NKB; ++kb)
+			pin(lv[kb]);
+#pragma unroll
+		for (int r = 0; r < 4; ++r)
+			pin(rl[r]);
+#pragma unroll
+		for (int kb = 0; kb < NKB; ++kb) {
+			const int c = 4 * kb + q4;
+			double v = (kb < 4 || c < kNU) ? lv[kb] : 0.0;
+			if (LEVEL == 3)
+				v = (rb >= 0) ? ((c == rb) ? 1.0 : 0.0) : v;
+			av[kb] = v;
+		}
+#pragma unroll
+		for (int r = 0; r < 4; ++r)
+			rvr[r] = (LEVEL == 3) ? rl[r] : 0.0 - rl[r];
+	}
+};
+
 #ifdef HOQP_PROFILE
 #define dbgp_proj (l.dbgp)
 #endif
@@ -1175,13 +1248,13 @@ __device__ __forceinline__ void project_task_mfma(Src &src, int rows, int nz, co
 		d4v acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
 		if (two) {
 #pragma unroll
-			for (int kb = 0; kb < NR / 4; ++kb) {
+			for (int kb = 0; kb < Src::NKB; ++kb) {
 				acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kb], bm[kb][0], acc0, 0, 0, 0);
 				acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kb], bm[kb][1], acc1, 0, 0, 0);
 			}
 		} else {
 #pragma unroll
-			for (int kb = 0; kb < NR / 4; ++kb)
+			for (int kb = 0; kb < Src::NKB; ++kb)
 				acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kb], bm[kb][0], acc0, 0, 0, 0);
 		}
 		// D[i = q4 + 4 r][j = j16 (+16)]: one store per held entry (projected entry, right-hand
@@ -1211,6 +1284,136 @@ __device__ __forceinline__ void project_task_mfma(Src &src, int rows, int nz, co
 		for (int i = 0; i < 3; ++i)
 			dbgp_proj[39 + i] += pt[i];
 #endif
+}
+
+// Level 0 of the fused entry (ConstructFloatingBaseEomTask, ho_qp_controller.cpp:351-366): Z = I and x = 0
+// (InitPrevProblemValuesToDefault, ho_qp_problem.cpp:119-128), so the projected block is the block itself:
+// A = [M_fb, -J_c,fb^T], r = b = -h_fb.  One column per lane, three rows each.
+__device__ __forceinline__ void wbc_project_level0(const WbcCtx &wx, int ld, const Lds &l)
+{
+	const int lane = lane_id(), c = lane & 31, r2 = lane >> 5;
+	const int jc0 = wbc_jcoff(wx, c);
+	const bool ism = c < kNU;
+	double v[3];
+#pragma unroll
+	for (int j = 0; j < 3; ++j) {
+		const int r = r2 + 2 * j;
+		const double *p = ism ? wx.M + r * kNU + c : wx.Jf + (jc0 >= 0 ? jc0 : 0) + r;
+		v[j] = *p;
+	}
+	const double hv = wx.h[lane < kNB ? lane : 0];
+#pragma unroll
+	for (int j = 0; j < 3; ++j)
+		pin(v[j]);
+#pragma unroll
+	for (int j = 0; j < 3; ++j) {
+		const int r = r2 + 2 * j;
+		st_if(c < wx.n, l.TV + r * ld + c, l.dump + lane, ism ? v[j] : 0.0 - v[j]);
+	}
+	st_if(lane < kNB, l.rhs + lane, l.dump + lane, 0.0 - hv);
+	wave_sync();
+}
+
+// Level 1 of the fused entry: ConstructJointTorqueTask (ho_qp_controller.cpp:332-349) ++
+// ConstructFrictionConeTask (:299-330), 24 + 4 n_c inequality rows, of which only 12 are multiplied:
+//   rows  0..11  [M_j, -J_c,j^T]              one 16-row tile on the matrix cores
+//   rows 12..23  the negated rows 0..11        written as the negated results (exact)
+//   rows 24..    friction pyramid, two non-zeros per row: +-Z[col + (t >> 1)] - mu Z[col + 2], straight from Z
+// Same values as the generated rows of wbc_entry<1> pushed through project_task_mfma.
+__device__ __forceinline__ void wbc_project_level1(const WbcCtx &wx, const WbcPrm &prm, const int (&jc)[NR / 4], int nz, int ld,
+						   const double (&bm)[NR / 4][2], const ProjDst dst, const Lds &l)
+{
+	const int lane = lane_id(), j16 = lane & 15, q4 = lane >> 4;
+	const bool two = nz + 1 > 16;
+	const int rr = j16 < kNJ ? j16 : 0;
+	const double *mrow = wx.M + (kNB + rr) * kNU;
+	const double *jrow = wx.Jf + kNB + rr;
+	double lv[NR / 4], hv[3];
+#pragma unroll
+	for (int kb = 0; kb < NR / 4; ++kb) {
+		const int c = 4 * kb + q4;
+		const double *pj = jrow + (jc[kb] >= 0 ? jc[kb] : 0);
+		const double *p = (kb < 4) ? mrow + c : (kb == 4 ? (c < kNU ? mrow + c : pj) : pj);
+		lv[kb] = *p;
+	}
+#pragma unroll
+	for (int r = 0; r < 3; ++r)
+		hv[r] = wx.h[kNB + q4 + 4 * r];
+	// friction rows: lane = (column j, half hf); contact i: rows 24 + 4 i + 2 hf + {0, 1}
+	const int fj = lane & 31, hf = lane >> 5;
+	const bool fz = fj < nz, fx = fj == nz;
+	double fa[4], fc[4];
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		const int ii = i < wx.nc ? i : 0;
+		// Q1 (:321-324): the pyramid lands on columns 6 + 3 leg (joint accelerations)
+		const int col = prm.friction_quirk ? kNB + wbc_pick(wx.clp, ii) * 3 : kNU + 3 * ii;
+		const ldsd *pa = fz ? l.Z + (col + hf) * ld + fj : l.x + (col + hf);
+		const ldsd *pc = fz ? l.Z + (col + 2) * ld + fj : l.x + (col + 2);
+		fa[i] = *pa;
+		fc[i] = *pc;
+	}
+#pragma unroll
+	for (int kb = 0; kb < NR / 4; ++kb)
+		pin(lv[kb]);
+#pragma unroll
+	for (int r = 0; r < 3; ++r)
+		pin(hv[r]);
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		pin(fa[i]);
+		pin(fc[i]);
+	}
+	double av[NR / 4];
+#pragma unroll
+	for (int kb = 0; kb < NR / 4; ++kb) {
+		const int c = 4 * kb + q4;
+		const double vj = (jc[kb] >= 0) ? 0.0 - lv[kb] : 0.0;
+		av[kb] = (kb < 4) ? lv[kb] : (kb == 4 ? (c < kNU ? lv[kb] : vj) : vj);
+	}
+	d4v acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+	if (two) {
+#pragma unroll
+		for (int kb = 0; kb < NR / 4; ++kb) {
+			acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kb], bm[kb][0], acc0, 0, 0, 0);
+			acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kb], bm[kb][1], acc1, 0, 0, 0);
+		}
+	} else {
+#pragma unroll
+		for (int kb = 0; kb < NR / 4; ++kb)
+			acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kb], bm[kb][0], acc0, 0, 0, 0);
+	}
+	// friction rows while the matrix cores work
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		const bool on = i < wx.nc && (fz || fx);
+		const double vp = fma(-prm.mu, fc[i], fa[i]), vm = fma(-prm.mu, fc[i], 0.0 - fa[i]);
+		const int row = 2 * kNJ + 4 * i + 2 * hf;
+		ldsd *d0 = fz ? dst.M + row * dst.ldm + fj : dst.rhs + row;
+		ldsd *d1 = fz ? dst.M + (row + 1) * dst.ldm + fj : dst.rhs + row + 1;
+		st_if(on, d0, l.dump + lane, fz ? vp : 0.0 - vp);
+		st_if(on, d1, l.dump + lane, fz ? vm : 0.0 - vm);
+	}
+	// D[i = q4 + 4 r][j = j16 (+16)], r < 3: rows i and 12 + i
+#pragma unroll
+	for (int cb = 0; cb < 2; ++cb) {
+		if (cb == 1 && !two)
+			continue;
+		const int j = 16 * cb + j16;
+		const bool isZ = j < nz, isX = j == nz;
+#pragma unroll
+		for (int r = 0; r < 3; ++r) {
+			const int i = q4 + 4 * r;
+			const double v = cb ? acc1[r] : acc0[r];
+			const double fu = fma(-1.0, hv[r], prm.tau_max);   // tau_max - h_j, :343
+			const double fl = fma(1.0, hv[r], -prm.tau_min);  // -(tau_min - h_j), :344
+			ldsd *du = isZ ? dst.M + i * dst.ldm + j : dst.rhs + i;
+			ldsd *dl = isZ ? dst.M + (kNJ + i) * dst.ldm + j : dst.rhs + kNJ + i;
+			st_if(isZ || isX, du, l.dump + lane, isX ? fu - v : v);
+			st_if(isZ || isX, dl, l.dump + lane, isX ? fl + v : 0.0 - v);
+		}
+	}
+	wave_sync();
 }
 
 #ifdef HOQP_PROFILE
@@ -1795,16 +1998,16 @@ __device__ __forceinline__ bool ref_replay(const SolveArgs &a, const Lds &l, int
 			const ProjDst dst = {l.TV, nzr, l.rhs};
 			if (WBC) {
 				if (j == 0) {
-					WbcLevelSrc<0> src(wx, a.wprm, l, jc);
+					WbcEntrySrc<0> src(wx, a.wprm, l, jc);
 					project_task_mfma(src, mj, nzr, bm, dst, l);
 				} else if (j == 2) {
-					WbcLevelSrc<2> src(wx, a.wprm, l, jc);
+					WbcEntrySrc<2> src(wx, a.wprm, l, jc);
 					project_task_mfma(src, mj, nzr, bm, dst, l);
 				} else if (j == 3) {
-					WbcLevelSrc<3> src(wx, a.wprm, l, jc);
+					WbcEntrySrc<3> src(wx, a.wprm, l, jc);
 					project_task_mfma(src, mj, nzr, bm, dst, l);
 				} else {
-					WbcLevelSrc<4> src(wx, a.wprm, l, jc);
+					WbcEntrySrc<4> src(wx, a.wprm, l, jc);
 					project_task_mfma(src, mj, nzr, bm, dst, l);
 				}
 			} else {
@@ -1971,33 +2174,33 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 					l.dbgp[43] += __builtin_amdgcn_s_memtime() - tb0_;
 #endif
 			}
+		} else if (WBC && k == 0) {
+			if (m > 0 && doA)
+				wbc_project_level0(wx, ld, l);
 		} else if (WBC) {  // fused entry (n <= 30: always the matrix-core path)
 			double bm[NR / 4][2];
 #ifdef HOQP_PROFILE
 			const unsigned long long tb0_ = __builtin_amdgcn_s_memtime();
 #endif
-			load_bm(bm, n, nz, ld, l);
+			if (k == 1) {
+				if (p > 0 && doD) {
+					load_bm(bm, n, nz, ld, l);
+					wbc_project_level1(wx, a.wprm, jc, nz, ld, bm, dstG, l);
+				}
+			} else if (m > 0 && doA) {
+				load_bm<kWbcKB>(bm, n, nz, ld, l);
+				if (k == 2) {
+					WbcLevelSrc<2> src(wx, l);
+					project_task_mfma(src, m, nz, bm, dstT, l);
+				} else {  // k == 3 (level 4 is handled above)
+					WbcLevelSrc<3> src(wx, l);
+					project_task_mfma(src, m, nz, bm, dstT, l);
+				}
+			}
 #ifdef HOQP_PROFILE
 			if (l.dbgp && lane == 0)
 				l.dbgp[42] += __builtin_amdgcn_s_memtime() - tb0_;
 #endif
-			if (k == 1) {
-				if (p > 0 && doD) {
-					WbcLevelSrc<1> src(wx, a.wprm, l, jc);
-					project_task_mfma(src, p, nz, bm, dstG, l);
-				}
-			} else if (m > 0 && doA) {
-				if (k == 0) {
-					WbcLevelSrc<0> src(wx, a.wprm, l, jc);
-					project_task_mfma(src, m, nz, bm, dstT, l);
-				} else if (k == 2) {
-					WbcLevelSrc<2> src(wx, a.wprm, l, jc);
-					project_task_mfma(src, m, nz, bm, dstT, l);
-				} else {  // k == 3 (level 4 is handled above)
-					WbcLevelSrc<3> src(wx, a.wprm, l, jc);
-					project_task_mfma(src, m, nz, bm, dstT, l);
-				}
-			}
 		} else if (nz < 32) {  // matrix-core path
 			double bm[NR / 4][2];
 			load_bm(bm, n, nz, ld, l);
