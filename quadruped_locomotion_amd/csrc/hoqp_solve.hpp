@@ -2123,6 +2123,7 @@ template <bool GATE, bool HARD, bool WBC>
 __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, LevelState &st, int inst, int k, int m, int p,
 					    const WbcCtx &wx, const int (&jc)[NR / 4])
 {
+	HOQP_STAMP(45);
 	const int lane = lane_id(), s = lane & 3, c = lane >> 2;
 	const int n = uni(st.n), ld = a.ld;
 	const int nz = uni(st.nz), P = HARD ? uni(st.P) : 0;
@@ -2859,6 +2860,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 	st.Pout += p;
 	wave_sync();
 	HOQP_STAMP(6);
+	HOQP_STAMP(46);	 // back-to-back with the previous one: what a stamp itself leaves in the next section
 
 	if (a.out.x_levels && lane < a.n)
 		a.out.x_levels[((size_t)inst * a.L + k) * a.n + lane] = (lane < n) ? l.x[lane] : 0.0;

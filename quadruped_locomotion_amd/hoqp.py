@@ -449,3 +449,32 @@ class HoQpSolver:
               "noalloc": self.lib.hoqp_solve_wbc_noalloc}[entry]
         self._check(fn(self.h, C.byref(wi), C.byref(wo), self._stream()), "hoqp_solve_wbc_" + entry)
         return out
+
+    def solve_wbc_host(self, inp):
+        """hoqp_solve_wbc_host: numpy arrays in host memory in, numpy arrays out (the entry the C++ shim's
+        CalcJointCmd uses; one H2D copy, one launch, one D2H copy through the handle's staging arenas;
+        returns when the results are in the output arrays)."""
+        import numpy as np
+        B = inp["M"].shape[0]
+        keep = []
+        wi = WbcInputs()
+        wi.batch = B
+        for name in ("M", "h", "Jfoot", "Jdotu", "footpos", "Jb", "q", "u", "base_cmd", "leg_cmd"):
+            arr = inp.get(name)
+            if arr is not None:
+                arr = np.ascontiguousarray(arr, dtype=np.float64)
+                keep.append(arr)
+                setattr(wi, name, arr.ctypes.data)
+        ct = np.ascontiguousarray(inp["contact"], dtype=np.int32)
+        keep.append(ct)
+        wi.contact = ct.ctypes.data
+        shapes = dict(x=(30, np.float64), qdd=(12, np.float64), tau=(12, np.float64), v=(40, np.float64),
+                      flags=(5, np.int32), eq_res_max=(5, np.float64), ineq_viol_max=(5, np.float64),
+                      level_res=(5, np.float64), active_mask=(None, np.uint64), status=(None, np.int32),
+                      iters=(5, np.int32), nz_levels=(5, np.int32))
+        out = {k: np.zeros((B,) if w is None else (B, w), dtype=dt) for k, (w, dt) in shapes.items()}
+        wo = WbcOutputs()
+        for name, arr in out.items():
+            setattr(wo, name, arr.ctypes.data)
+        self._check(self.lib.hoqp_solve_wbc_host(self.h, C.byref(wi), C.byref(wo)), "hoqp_solve_wbc_host")
+        return out

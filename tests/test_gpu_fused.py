@@ -226,3 +226,19 @@ def test_skip_unread_slack_levels(solver_factory, oracle):
     for key in ("x", "tau"):
         err = np.abs(b[key] - ref[key]) / np.maximum(1.0, np.abs(ref[key]))
         assert err.max() <= 1e-6, (key, err.max())
+
+
+def test_host_entry_batched(solver_factory):
+    """hoqp_solve_wbc_host at batch sizes > 1 (the shim only drives it with one state): pageable numpy
+    buffers in and out, bit-identical to the device-resident entry on the same states; a second, smaller
+    call reuses the handle's staging arenas."""
+    s = solver_factory("reference")
+    for B, seed in ((300, 21), (37, 22)):
+        inp = am.make_wbc_inputs(am.sample_states(B, seed, "trot"))
+        h = s.solve_wbc_host(inp)
+        d = {k: v.cpu().numpy() for k, v in s.solve_wbc(s.to_device(inp)).items()}
+        s.synchronize()
+        assert np.all(h["status"] == 0)
+        for key in ("x", "qdd", "tau", "v", "flags", "level_res", "eq_res_max", "ineq_viol_max", "iters", "nz_levels", "status"):
+            assert np.array_equal(h[key], d[key]), key
+        assert np.array_equal(h["active_mask"], d["active_mask"].astype(np.uint64))

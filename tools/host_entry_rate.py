@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rate of the host-buffer entry hoqp_solve_wbc_host (never the bench's `value`, which is
+HBM-resident): numpy buffers in pageable host memory in, numpy buffers out, one call =
+memcpy into the pinned arena + one H2D copy + one launch + one D2H copy + memcpy out.
+
+usage: python tools/host_entry_rate.py [batch] [reps]
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from quadruped_locomotion_amd import anymal_model as am  # noqa: E402
+from quadruped_locomotion_amd import hoqp  # noqa: E402
+
+
+def main():
+    batch = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+    s = hoqp.HoQpSolver(hoqp.default_config("reference"))
+    inp = am.make_wbc_inputs(am.sample_states(batch, 1234, "stance"))
+    in_bytes = sum(v.nbytes for v in inp.values())
+    for _ in range(5):
+        out = s.solve_wbc_host(inp)
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = s.solve_wbc_host(inp)
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    med = ts[len(ts) // 2]
+    out_bytes = sum(v.nbytes for v in out.values())
+    print(json.dumps({"entry": "hoqp_solve_wbc_host", "batch": batch, "reps": reps, "median_ms": med * 1e3,
+                      "p99_ms": ts[int(0.99 * (len(ts) - 1))] * 1e3, "solves_per_s": batch / med,
+                      "host_bytes_in": in_bytes, "host_bytes_out": out_bytes,
+                      "status_nonzero": int((out["status"] != 0).sum())}))
+
+
+if __name__ == "__main__":
+    main()
