@@ -476,9 +476,9 @@ static int launch_solve(hoqp_handle *h, SolveArgs &a, hipStream_t s, bool wbc, b
 			fprintf(stderr, "[hoqp profile] update parts: rows=%.0f of which issue=%.0f wait=%.0f dots=%.0f stores=%.0f\n", sum[27] / batch, sum[28] / batch, sum[29] / batch, sum[30] / batch, sum[31] / batch);
 			fprintf(stderr, "[hoqp profile] EQP rank-deficient LS: sum(nunp)=%.3f  #(nunp>4)=%.4f #(nunp>8)=%.4f #(nb>32)=%.4f per instance\n",
 				sum[23] / batch, sum[24] / batch, sum[25] / batch, sum[26] / batch);
-			fprintf(stderr, "[hoqp profile] projection parts: fetch issue=%.0f wait for operands=%.0f multiply+store=%.0f B operand=%.0f level-4 copy=%.0f level prologue=%.0f between levels=%.0f stamp echo=%.0f\n",
+			fprintf(stderr, "[hoqp profile] projection parts: fetch issue=%.0f wait for operands=%.0f multiply+store=%.0f B operand=%.0f level-4 copy=%.0f level prologue=%.0f level end=%.0f back-edge=%.0f level head=%.0f stamp echo=%.0f\n",
 				sum[39] / batch, sum[40] / batch, sum[41] / batch, sum[42] / batch, sum[43] / batch, sum[44] / batch,
-				sum[45] / batch, sum[46] / batch);
+				sum[49] / batch, sum[48] / batch, sum[45] / batch, sum[46] / batch);
 			if (sum[32] > 0)
 				fprintf(stderr, "[hoqp profile] reference replay: %.4f per instance; cycles per replay: project=%.0f regsolve=%.0f xr=%.0f lu=%.0f kernel=%.0f product=%.0f\n",
 					sum[32] / batch, sum[33] / sum[32], sum[34] / sum[32], sum[35] / sum[32], sum[36] / sum[32],

@@ -9,6 +9,7 @@
 //
 // Algorithm: DESIGN.md section 3.  Reference: src/control/ho_qp/ho_qp_problem.cpp:11-357.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 
 #include "../../include/hoqp.h"
@@ -26,7 +27,7 @@ constexpr int SROW = 36;  // row stride of the task staging buffer of the n_z ==
 			  // aligned rows); the matrix-core projection loads its operand from global memory
 constexpr int XROWS = 16; // dumped unpivoted columns (rank-deficient least squares); aliases S
 constexpr int CHUNK = 16; // task rows per projection pass (one 16 x K matrix-core operand tile)
-constexpr int kDbgSlots = 48;	  // HOQP_PROFILE builds: cycle-stamp slots per instance
+constexpr int kDbgSlots = 56;	  // HOQP_PROFILE builds: cycle-stamp slots per instance
 constexpr int kReplaySteps = 2;	  // inequality-only levels whose x step the reference replay can carry
 // the reference replay runs when eps / (smallest pivot)^2 of an unconstrained level exceeds this
 constexpr double kReplayTau = 3e-8;
@@ -2119,10 +2120,16 @@ __device__ __forceinline__ bool ref_replay(const SolveArgs &a, const Lds &l, int
 // inequality level under GATE, i.e. the reference's WBC hierarchy: no hard rows, no working set,
 // no phase 1, no multipliers -- all of that code is compiled out).
 // WBC: the task rows come from the generator of wbc_tasks.hpp (fused entry) instead of a.A / a.D.
-template <bool GATE, bool HARD, bool WBC>
-__device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, LevelState &st, int inst, int k, int m, int p,
+// KC: the level index as a compile-time constant (-1: run-time, k_rt).  The fused WBC kernel of the reference
+// semantics runs its five levels as five specialised copies: with the level known, each copy carries only its
+// own projection and only the solver paths its shape can reach (the QP code exists in level 1 alone), and the
+// level loop has no far backward jump (measured: ~2 k cycles of instruction fetch per back-edge of the
+// 380 KB loop body).
+template <bool GATE, bool HARD, bool WBC, int KC = -1>
+__device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, LevelState &st, int inst, int k_rt, int m, int p,
 					    const WbcCtx &wx, const int (&jc)[NR / 4])
 {
+	const int k = (KC >= 0) ? KC : k_rt;
 	HOQP_STAMP(45);
 	const int lane = lane_id(), s = lane & 3, c = lane >> 2;
 	const int n = uni(st.n), ld = a.ld;
@@ -3138,7 +3145,11 @@ __global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
 	asm volatile("" ::"v"(warm));  // the warming loads must be issued; their values are not used
 
 	HOQP_STAMP(0);
-	for (int k = 0; k < a.L; ++k) {
+	// one level; kc: std::integral_constant<int, level> for a specialised copy, <int, -1> for the run-time loop
+	auto run_level = [&](auto kc, int k_rt) {
+		constexpr int KC = decltype(kc)::value;
+		const int k = (KC >= 0) ? KC : k_rt;
+		HOQP_STAMP(48);	 // loop back-edge
 		int m, p;
 		if (WBC) {
 			m = wbc_m(wx, k);
@@ -3172,11 +3183,22 @@ __global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
 				a.out.x_levels[((size_t)inst * a.L + k) * a.n + lane] = (lane < n) ? l.x[lane] : 0.0;
 			st.Pout += p;
 			wave_sync();
-			continue;
+			return;
 		}
-		solve_level<GATE, HARD, WBC>(a, l, st, inst, k, m, p, wx, jc);
+		solve_level<GATE, HARD, WBC, KC>(a, l, st, inst, k, m, p, wx, jc);
+		HOQP_STAMP(49);	 // per-level outputs after the last stamp of the level
+	};
+	if (WBC && GATE && !HARD) {
+		// the reference's WBC hierarchy (fill_args: L == 5): five specialised copies
+		run_level(std::integral_constant<int, 0>{}, 0);
+		run_level(std::integral_constant<int, 1>{}, 1);
+		run_level(std::integral_constant<int, 2>{}, 2);
+		run_level(std::integral_constant<int, 3>{}, 3);
+		run_level(std::integral_constant<int, 4>{}, 4);
+	} else {
+		for (int k = 0; k < a.L; ++k)
+			run_level(std::integral_constant<int, -1>{}, k);
 	}
-
 	// ---- final x and the CheckSolutionValid flags (helper_functions.hpp:63-91) ----
 	double xi = (lane < n) ? l.x[lane] : 0.0;
 	if (__ballot(!isfinite(xi)))
