@@ -2135,8 +2135,18 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 	const int n = uni(st.n), ld = a.ld;
 	const int nz = uni(st.nz), P = HARD ? uni(st.P) : 0;
 	const int nstore = a.n;
-	m = uni(m);
-	p = uni(p);
+	if (WBC && KC >= 0) {
+		// a specialised copy: m and p are expressions of the (uniform) contact counts, and the shape facts
+		// of the WBC hierarchy are told to the compiler so that each copy keeps only the slot counts and
+		// solver paths it can reach (n = 18 + 3 n_c; level 0 starts from Z = I)
+		__builtin_assume(n >= kNU && n <= kNX);
+		__builtin_assume(nz >= 0 && nz <= n);
+		if (KC == 0)
+			__builtin_assume(nz == n);
+	} else {
+		m = uni(m);
+		p = uni(p);
+	}
 	const int Pn = P + p;
 	const bool consider = (nz > 0) && (GATE ? (p > 0) : (p > 0 || P > 0));
 	// stored rows are still needed by a later level?  (else they are neither rotated nor kept)
@@ -2153,7 +2163,8 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 	// A level with more equality rows than free coordinates is first tried "tall": QR of A Z
 	// itself; with full column rank that is the whole answer (unique y, empty null space).
 	// A rank-deficient tall level falls back to the general path (second pass of the loop).
-	bool tall = m > nz && nz > 0;
+	// (fused WBC: level 0 is 6 x n and level 2 is 3 n_c x (n_z >= 12 + 3 n_c): never tall)
+	bool tall = (WBC && (KC == 0 || KC == 2)) ? false : (m > nz && nz > 0);
 	// A level without inequality rows of its own that has to respect stored rows (paper
 	// semantics) first tries its unconstrained optimum: if no stored row objects, that is the
 	// answer and the active-set loop is skipped.
@@ -3082,6 +3093,9 @@ __global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
 		wx.nc = uni(wx.nc);
 		wx.ns = uni(wx.ns);
 		wx.n = uni(wx.n);
+		__builtin_assume(wx.nc >= 0 && wx.nc <= 4);
+		__builtin_assume(wx.ns >= 0 && wx.ns <= 4);
+		__builtin_assume(wx.n == kNU + 3 * wx.nc);
 #pragma unroll
 		for (int kb = 4; kb < NR / 4; ++kb)
 			jc[kb] = wbc_jcoff(wx, 4 * kb + (lane >> 4));
