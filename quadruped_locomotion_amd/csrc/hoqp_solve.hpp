@@ -28,7 +28,6 @@ constexpr int SROW = 36;  // row stride of the task staging buffer of the n_z ==
 constexpr int XROWS = 16; // dumped unpivoted columns (rank-deficient least squares); aliases S
 constexpr int CHUNK = 16; // task rows per projection pass (one 16 x K matrix-core operand tile)
 constexpr int kDbgSlots = 56;	  // HOQP_PROFILE builds: cycle-stamp slots per instance
-constexpr int kReplaySteps = 2;	  // inequality-only levels whose x step the reference replay can carry
 // the reference replay runs when eps / (smallest pivot)^2 of an unconstrained level exceeds this
 constexpr double kReplayTau = 3e-8;
 
@@ -71,7 +70,7 @@ inline int lds_leading_dim(int n)
 
 // byte offsets of the LDS arrays (shared by host sizing and device addressing)
 struct LdsOff {
-	int Z, x, G, g, vs, s, c, TV, S, BL, r0, rho, a0, tau, rdiag, rhs, X, tmp, dump, b3, xstep, pivlane, W, xlane, colpos, vlist, total;
+	int Z, x, G, g, vs, s, c, TV, S, BL, r0, rho, a0, tau, rdiag, rhs, X, tmp, dump, b3, pivlane, W, xlane, colpos, vlist, total;
 };
 
 __host__ __device__ inline LdsOff lds_offsets(const SolveArgs &a)
@@ -105,7 +104,6 @@ __host__ __device__ inline LdsOff lds_offsets(const SolveArgs &a)
 	o.tmp = take(8 * kWave);
 	o.dump = take(8 * kWave);  // per-lane sink of predicated-off stores
 	o.b3 = take(8 * 24);	   // fused WBC entry: right-hand side of the tracking level
-	o.xstep = take(8 * NR * kReplaySteps);  // x steps of inequality-only levels (reference replay)
 	o.pivlane = take(4 * NR);
 	o.W = take(4 * NR);
 	o.xlane = take(4 * XROWS);
@@ -117,7 +115,7 @@ __host__ __device__ inline LdsOff lds_offsets(const SolveArgs &a)
 
 #ifdef __HIP_DEVICE_COMPILE__
 struct Lds {
-	ldsd *Z, *x, *G, *g, *vs, *s, *c, *TV, *S, *BL, *r0, *rho, *a0, *tau, *rdiag, *rhs, *X, *tmp, *dump, *b3, *xstep;
+	ldsd *Z, *x, *G, *g, *vs, *s, *c, *TV, *S, *BL, *r0, *rho, *a0, *tau, *rdiag, *rhs, *X, *tmp, *dump, *b3;
 	ldsi *pivlane, *W, *xlane, *colpos, *vlist;
 	unsigned long long *dbgp;  // HOQP_PROFILE builds: this instance's cycle-stamp slots (else null)
 };
@@ -146,7 +144,6 @@ __device__ __forceinline__ Lds lds_bind(const SolveArgs &a, HOQP_LDS char *base)
 	l.tmp = (ldsd *)(base + o.tmp);
 	l.dump = (ldsd *)(base + o.dump);
 	l.b3 = (ldsd *)(base + o.b3);
-	l.xstep = (ldsd *)(base + o.xstep);
 	l.pivlane = (ldsi *)(base + o.pivlane);
 	l.W = (ldsi *)(base + o.W);
 	l.xlane = (ldsi *)(base + o.xlane);
@@ -1443,7 +1440,6 @@ struct LevelState {
 	int Pout;  // inequality rows emitted so far (offset of this level's slacks in out.v)
 	int status;
 	int replay_ok;	// every level so far can be replayed literally (see ref_replay)
-	int nskip;	// inequality-only levels whose x step is stored in l.xstep
 	unsigned long long t_last;
 };
 
@@ -1957,12 +1953,16 @@ __device__ __forceinline__ bool ref_replay(const SolveArgs &a, const Lds &l, int
 	if (n >= NR)
 		return false;
 	wave_sync();
+	// x_{k-1}: the fast path's own (its earlier levels were either well conditioned -- the eps term is below
+	// 3e-8 of the step there, whatever the basis -- or replayed themselves); the level update has just added
+	// the step l.S to it.  Only the BASIS of the earlier levels has to be redone in the reference's
+	// coordinates, not their solves.
 	if (lane < NR)
-		xr[lane] = 0.0;
+		xr[lane] = (lane < n) ? l.x[lane] - l.S[lane] : 0.0;
 	wave_sync();
 	const ldsd *Zr = l.G;
 	bool zident = true;  // Zr is the identity so far (no null tests on LDS pointers: offset 0 is a valid address)
-	int nzr = n, zoff = 0, slot = 0;
+	int nzr = n, zoff = 0;
 	for (int j = 0; j <= k; ++j) {
 		int mj, pj;
 		if (WBC) {
@@ -1974,16 +1974,7 @@ __device__ __forceinline__ bool ref_replay(const SolveArgs &a, const Lds &l, int
 		}
 		if (nzr == 0)
 			break;
-		if (pj > 0) {  // an inequality-only level: the fast path's own step (it lies in the common range)
-			if (slot >= kReplaySteps)
-				return false;
-			if (lane < n)
-				xr[lane] += l.xstep[slot * NR + lane];
-			++slot;
-			wave_sync();
-			continue;
-		}
-		if (mj == 0)
+		if (pj > 0 || mj == 0)	// an inequality-only level leaves the null space as it is
 			continue;
 		if (j == k && nzr != nz_entry)
 			return false;  // the LU's rank decisions differ from the QR's: leave the fast answer
@@ -2017,9 +2008,10 @@ __device__ __forceinline__ bool ref_replay(const SolveArgs &a, const Lds &l, int
 			}
 		}
 		RSTAMP(33);
+		if (j == k) {
 		lds_reg_solve(l.TV, l.rhs, mj, nzr, a.eps, wv, zv);
 		RSTAMP(34);
-		if (j == k) {  // |A_k x_k - b_k|^2 at the regularised optimum
+		{  // |A_k x_k - b_k|^2 at the regularised optimum
 			double ri = 0.0;
 			if (lane < mj) {
 				ri = l.rhs[lane];
@@ -2050,6 +2042,7 @@ __device__ __forceinline__ bool ref_replay(const SolveArgs &a, const Lds &l, int
 		}
 		wave_sync();
 		RSTAMP(35);
+		}
 		if (j < k) {
 			const int rank = uni(lds_fullpivlu(l.TV, mj, nzr, l.colpos));
 			RSTAMP(36);
@@ -2841,17 +2834,10 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 		}
 		if (__ballot(nonfinite))
 			st.status |= HOQP_STATUS_NONFINITE;
-		// bookkeeping of the reference replay: a QP level with equality rows cannot be replayed; an
-		// inequality-only level is carried as its x step
-		if (consider) {
-			if (m > 0 || st.nskip >= kReplaySteps) {
-				st.replay_ok = 0;
-			} else {
-				if (lane < NR)
-					l.xstep[st.nskip * NR + lane] = (lane < n) ? l.S[lane] : 0.0;
-				++st.nskip;
-			}
-		}
+		// bookkeeping of the reference replay: the null space of a QP level with equality rows is not
+		// rebuilt by it (an inequality-only level leaves the null space alone)
+		if (consider && m > 0)
+			st.replay_ok = 0;
 	}
 #ifndef HOQP_NO_REPLAY
 	if (__builtin_expect(a.eps != 0.0 && !consider && !keep_rows && st.replay_ok && m > 0 && rank > 0 && k > 0 &&
@@ -3083,7 +3069,6 @@ __global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
 	LevelState st;
 	st.status = 0;
 	st.replay_ok = 1;
-	st.nskip = 0;
 	WbcCtx wx = {};
 	int jc[NR / 4] = {-1, -1, -1, -1, -1, -1, -1, -1};
 	if (WBC) {
@@ -3178,12 +3163,6 @@ __global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
 		}
 		if (GATE && a.skip_unread && !a.out.v && m == 0 && p > 0 && k >= a.last_ineq_use) {
 			// HOQP_OPT_SKIP_UNREAD_SLACK_LEVELS: nobody reads this level's rows (Q2) or slacks (v == NULL)
-			if (lane < NR && st.nskip < kReplaySteps)
-				l.xstep[st.nskip * NR + lane] = 0.0;
-			if (st.nskip < kReplaySteps)
-				++st.nskip;
-			else
-				st.replay_ok = 0;
 			if (lane == 0) {
 				const size_t o = (size_t)inst * a.L + k;
 				if (a.out.level_res)
