@@ -189,6 +189,8 @@ def main():
                     help="contact patterns: i.i.d. masks (stance / trot / three) or, for crawl, the pattern and swing "
                          "commands of the reference's crawl gait at random phases (hoqp_gait_sample_batched)")
     ap.add_argument("--seed", type=int, default=None)
+    ap.add_argument("--pipeline-streams", type=int, default=2,
+                    help="extra, non-headline measurement after the timed region: this many batches in flight (0/1: off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=512)
     ap.add_argument("--mu", type=float, default=None, help="friction coefficient (default: the reference's)")
@@ -335,6 +337,36 @@ def main():
         lat.append((time.perf_counter() - a) * 1e3)
     lat = np.array(lat)
 
+    # Two batches in flight (outside the timed region, never `value`): the same step issued alternately on
+    # two streams with two handles and two output sets.  4096 states are exactly four per wave slot, so a
+    # single launch ends with most slots idle while the slowest instances finish; a second batch in flight
+    # fills that tail.  Reported to show what the launch quantisation costs.
+    pipelined = None
+    if world == 1 and args.pipeline_streams > 1 and not gather_in_step:
+        ns = args.pipeline_streams
+        streams = [torch.cuda.Stream() for _ in range(ns)]
+        solvers = [hoqp.HoQpSolver(solver.cfg) for _ in range(ns)]
+        outs = [solver.alloc_wbc_outputs(nloc) for _ in range(ns)]
+        if args.skip_unread_slack:
+            for o in outs:
+                o["v"] = None
+        torch.cuda.synchronize()
+        reps = max(args.steps, 20)
+        for timed in (False, True):
+            torch.cuda.synchronize()
+            p0 = time.perf_counter()
+            for i in range(reps):
+                with torch.cuda.stream(streams[i % ns]):
+                    solvers[i % ns].solve_wbc(dinp, outs[i % ns])
+            torch.cuda.synchronize()
+            p1 = time.perf_counter()
+        same = all(bool(torch.equal(outs[j]["x"], out["x"])) for j in range(ns))
+        pipelined = {"streams": ns, "steps": reps, "value": nloc * reps / (p1 - p0), "unit": "solves/s",
+                     "ms_per_step": (p1 - p0) / reps * 1e3, "x_identical_to_single_stream": same,
+                     "note": "batches of the same size issued alternately on %d streams; not the headline" % ns}
+        for sv in solvers:
+            sv.close()
+
     gather_ms, stats = None, None
     if world > 1 and not args.no_gather:
         collect()  # warm-up of the communicator
@@ -406,6 +438,7 @@ def main():
                                  "batch's contact patterns; active-set iterations are not counted as FLOPs"},
             "latency_ms": {"p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99)),
                            "max": float(lat.max()), "batches": int(lat.size)},
+            "pipelined": pipelined,
             "solver": {"status_nonzero": int((status != 0).sum()), "iters_level1_mean": float(iters[:, 1].mean()),
                        "iters_max": int(iters.max()),
                        # active-set steps per instance, summed over the levels: histogram 0,1,2,...
