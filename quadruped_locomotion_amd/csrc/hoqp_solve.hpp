@@ -2699,12 +2699,14 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 			wave_sync();
 			l.tmp[lane] = (lane < nz) ? pi : 0.0;
 			wave_sync();
-			rows_dot<4>(l.G, Pn, ld, nz, l.tmp, l.c);
+			if (WBC && KC >= 0)
+				rows_dot<3>(l.G, Pn, ld, nz, l.tmp, l.c);  // at most 40 rows
+			else
+				rows_dot<4>(l.G, Pn, ld, nz, l.tmp, l.c);
 			rows_dot<2>(l.BL, mB, ld, rank, l.tmp, l.a0);
 			wave_sync();
 			const double ci = sel(lane < Pn, l.c[lane < Pn ? lane : 0]);
 			const double a0 = sel(lane < mB, l.a0[lane < mB ? lane : 0]);
-			const double q0 = wave_sum(a0 * rj), q1 = wave_sum(a0 * a0);
 			// ratio test on hard rows outside the working set
 			int blk = -1;
 			double t_hard = 1e300;
@@ -2717,6 +2719,17 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 				if (!(t_hard < 1e299))
 					blk = -1;
 			}
+			// The step p minimises the model with the violated set V held fixed, so its directional
+			// derivative at t = 1 is zero.  Every s_i + t c_i is linear in t: if at t = 1 no row outside V
+			// is violated and no row of V has gone negative (an under-determined step takes the rows of V
+			// exactly to zero), the positive part was V all along [0, 1] and t = 1 is the exact minimiser of
+			// the convex piecewise quadratic: no search (the usual last step of an instance).
+			const double s1 = si + ci;
+			const bool bad1 = isSoft && (viol ? (s1 < -tolv) : (s1 > tolv));
+			const bool fullstep = __ballot(bad1) == 0ull && !(t_hard < 1.0);
+			double t_star = 1.0;
+			if (!fullstep) {
+			const double q0 = wave_sum(a0 * rj), q1 = wave_sum(a0 * a0);
 			// exact line search on the piecewise quadratic along p
 			double tb = 1e300;
 			if (isSoft && ci != 0.0 && ((si > tolv && ci < 0.0) || (si <= tolv && ci > 0.0))) {
@@ -2755,13 +2768,13 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 				sv = si + t_lo * ci;
 				d_lo = q0 + q1 * t_lo + wave_sum((isSoft && sv > 0.0) ? ci * sv : 0.0);
 			}
-			double t_star;
 			if (d_lo >= 0.0)
 				t_star = t_lo;
 			else if (slope > 0.0)
 				t_star = fmin(t_lo - d_lo / slope, t_hi);
 			else
 				t_star = (t_hi < 1e299) ? t_hi : t_lo;
+			}
 			const double t = fmin(t_star, t_hard);
 			prev_full = fabs(t - 1.0) <= 1e-9 && !(t_hard <= t_star && blk >= 0);
 			prev_vmask = vmask;
