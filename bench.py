@@ -189,8 +189,10 @@ def main():
                     help="contact patterns: i.i.d. masks (stance / trot / three) or, for crawl, the pattern and swing "
                          "commands of the reference's crawl gait at random phases (hoqp_gait_sample_batched)")
     ap.add_argument("--seed", type=int, default=None)
-    ap.add_argument("--pipeline-streams", type=int, default=2,
-                    help="extra, non-headline measurement after the timed region: this many batches in flight (0/1: off)")
+    ap.add_argument("--pipeline-streams", type=int, default=0,
+                    help="extra, non-headline measurement after the timed region: this many batches in flight on as "
+                         "many streams (default off, so that a rocprofv3 trace of the default command holds no "
+                         "overlapped launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=512)
     ap.add_argument("--mu", type=float, default=None, help="friction coefficient (default: the reference's)")

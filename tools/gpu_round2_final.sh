@@ -8,6 +8,7 @@ timeout -k 10 300 python bench.py --no-cpu-baseline --contact three > gpurun_out
 timeout -k 10 300 python bench.py --no-cpu-baseline --skip-unread-slack > gpurun_out/rocprof/bench_skip.json || exit 1
 timeout -k 10 500 python bench.py --workload c4 --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/rocprof/bench_c4.json || exit 1
 timeout -k 10 300 python bench.py --no-cpu-baseline --batch 65536 --steps 50 > gpurun_out/rocprof/bench_65536.json || exit 1
+timeout -k 10 300 python bench.py --no-cpu-baseline --pipeline-streams 2 > gpurun_out/rocprof/bench_pipelined.json || exit 1
 for f in full paper trot three skip c4 65536; do python - "$f" <<'PY'
 import json, sys
 d = json.load(open("gpurun_out/rocprof/bench_%s.json" % sys.argv[1]))
