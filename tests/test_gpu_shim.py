@@ -108,3 +108,19 @@ def test_bench_two_rank_rehearsal():
     st = d["config"]["reduced_stats"]
     assert st["instances"] == 8191 and st["status_nonzero"] == 0 and np.isfinite(st["eq_res_max"])
     assert d["value"] > 0 and d["config"]["gather_ms"] > 0
+
+
+def test_bench_pipelined_option():
+    """bench.py --pipeline-streams 2: the extra two-batches-in-flight measurement (two handles, two streams,
+    two output sets) gives the same x as the single-stream step and is reported beside, not as, the value."""
+    import json
+    import sys
+
+    root = os.path.dirname(HERE)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--batch", "1024", "--steps", "5",
+           "--warmup", "1", "--latency-batches", "5", "--pipeline-streams", "2"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["pipelined"]["streams"] == 2 and d["pipelined"]["x_identical_to_single_stream"] is True
+    assert d["pipelined"]["value"] > 0 and d["value"] > 0 and d["n_gpus"] == 1
