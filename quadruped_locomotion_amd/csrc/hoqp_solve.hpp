@@ -1565,6 +1565,67 @@ __device__ __forceinline__ double eqp_step(const SolveArgs &a, const Lds &l, Lev
 	return pi;
 }
 
+// Equality-constrained step of an all-soft level (no least-squares rows, no working set) with at most 8
+// violated rows V, through the small side: p = -G_V' (G_V G_V')^-1 s_V is the minimum-norm step that takes
+// the rows of V to zero -- the same p as the factorization of the 8 columns of G_V' gives, at the price of
+// an 8 x 8 Gram matrix (one entry per lane), an 8 x 8 Gauss-Jordan and one combination of the rows.
+// Squaring the condition number is harmless while it is small: accepted only if the smallest pivot is above
+// 1e-4 of the largest diagonal entry (kappa(G_V) < 100); otherwise (dependent or nearly dependent rows)
+// the caller factors as usual.  Returns false in that case.
+__device__ __forceinline__ bool eqp_dual8(const Lds &l, int nz, int nV, int ld, double *p_out)
+{
+	const int lane = lane_id(), gi = lane >> 3, gj = lane & 7;
+	const int ri = l.vlist[gi < nV ? gi : 0], rj = l.vlist[gj < nV ? gj : 0];
+	const ldsd *ra = l.G + ri * ld, *rb = l.G + rj * ld;
+	double g0 = 0.0, g1 = 0.0;
+	for (int k0 = 0; k0 < nz; k0 += 8) {
+		double av[8], bv[8];
+#pragma unroll
+		for (int u = 0; u < 8; ++u) {
+			const int kk = (k0 + u < nz) ? k0 + u : 0;
+			av[u] = ra[kk];
+			bv[u] = rb[kk];
+		}
+#pragma unroll
+		for (int u = 0; u < 8; ++u) {
+			pin(av[u]);
+			pin(bv[u]);
+		}
+#pragma unroll
+		for (int u = 0; u < 8; ++u) {
+			const double t = sel(k0 + u < nz, av[u]);
+			if (u & 1)
+				g1 = fma(t, bv[u], g1);
+			else
+				g0 = fma(t, bv[u], g0);
+		}
+	}
+	const double gg = g0 + g1;
+	const bool inb = gi < nV && gj < nV;
+	const double dmax = wave_max((inb && gi == gj) ? gg : 0.0);
+	const double mval = inb ? gg : ((gi == gj) ? 1.0 : 0.0);
+	const double gval = (gi < nV) ? 0.0 - l.s[ri] : 0.0;
+	double minpiv;
+	const double lam = gauss_jordan8_piv(mval, gval, &minpiv);
+	if (!(minpiv > 1e-4 * dmax && dmax > 0.0))
+		return false;
+	// p_k = sum_i G[v_i][k] lam_i, one coordinate per lane
+	const int kk = lane < nz ? lane : 0;
+	double gk[8];
+#pragma unroll
+	for (int i = 0; i < 8; ++i)
+		gk[i] = l.G[__builtin_amdgcn_readlane(ri, 8 * i) * ld + kk];
+#pragma unroll
+	for (int i = 0; i < 8; ++i)
+		pin(gk[i]);
+	double p = 0.0;
+#pragma unroll
+	for (int i = 0; i < 8; ++i)
+		p = (i < nV) ? fma(gk[i], readlane_d(lam, 8 * i), p) : p;
+	*p_out = (lane < nz) ? p : 0.0;
+	return true;
+}
+
 // Level update on the rows of Z and G (row r = c + 16*slot):  d_r = row_r . y  -> l.S[r], then
 // the rows lose their first `rank` coordinates (shifted store).  y is in l.tmp.
 template <int NS>
@@ -2639,6 +2700,13 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 			HOQP_STAMP(5);
 			double pi = 0.0;
 			if (!(prev_full && vmask == prev_vmask)) {
+				wave_sync();
+				if (!HARD && mB == 0 && nV >= 1 && nV <= 8 && nV <= nz && eqp_dual8(l, nz, nV, ld, &pi)) {
+#ifdef HOQP_PROFILE
+					if (a.dbg && lane == 0)
+						a.dbg[(size_t)blockIdx.x * kDbgSlots + 50] += 1;  // steps through the small side
+#endif
+				} else
 				pi = eqp_step<HARD>(a, l, st, nz, rank, mB, w, nV, &k1, &overflow);
 				if (overflow) {
 					st.status |= HOQP_STATUS_WORKSPACE;
