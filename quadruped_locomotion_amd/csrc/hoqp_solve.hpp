@@ -1552,6 +1552,10 @@ __device__ __forceinline__ double eqp_step(const SolveArgs &a, const Lds &l, Lev
 		a.dbg[(size_t)blockIdx.x * kDbgSlots + 24] += (nunp > 4);
 		a.dbg[(size_t)blockIdx.x * kDbgSlots + 25] += (nunp > 8);
 		a.dbg[(size_t)blockIdx.x * kDbgSlots + 26] += (nunp > 0 && k2 - k1 + nunp > 32);
+		a.dbg[(size_t)blockIdx.x * kDbgSlots + 51] += (nb <= 16);
+		a.dbg[(size_t)blockIdx.x * kDbgSlots + 52] += (nb <= 16 && nunp == 0);
+		a.dbg[(size_t)blockIdx.x * kDbgSlots + 53] += nb;
+		a.dbg[(size_t)blockIdx.x * kDbgSlots + 54] += (nb <= 8);
 	}
 #endif
 	double q = ls_solve_reg(k1, k2, w, ncol, nunp, 0.0, ld, nullptr, l);
