@@ -383,10 +383,33 @@ __device__ __forceinline__ int panel_factor(double (&x)[NSP][NT], int (&pos)[NSP
 	return panel_factor_t<NSP>(x, pos, qlo, qhi, nr, k0, rtol, l, dbgp);
 }
 
+// Z = I (n x n, leading dimension ld): InitPrevProblemValuesToDefault, ho_qp_problem.cpp:119-128
+__device__ __forceinline__ void lds_set_identity(ldsd *Z, int n, int ld)
+{
+	const int lane = lane_id();
+	// (row, column) of entry idx advance by 64 entries per trip without a division per trip
+	const int qstep = kWave / ld, rstep = kWave - qstep * ld;
+	int r = lane / ld, c = lane - r * ld;
+	for (int idx = lane; idx < n * ld; idx += kWave) {
+		Z[idx] = (r == c) ? 1.0 : 0.0;
+		r += qstep;
+		c += rstep;
+		if (c >= ld) {
+			c -= ld;
+			++r;
+		}
+	}
+}
+
 // rows <- rows * H_ka ... H_(kb-1): reflectors [ka, kb) applied from the right to row-major
 // rows.  Row r = c + 16*slot is a vector owned by quad c; rows r < n0 come from A0, the rest
 // from A1.
-template <int NS>
+// IDENT: the rows of A0 are the rows of the identity and are not read (level 0 of a hierarchy starts from
+// Z = I: the rotation then writes Z = Q without Z ever having been initialised).
+// UPDATE: the level update in the same pass (the level's y, rotated coordinates, is already in l.tmp): after
+// the rotation the row is still in registers, so d_r = row_r . y -> l.S[r] and the row is stored without its
+// first kb coordinates (Z_k = Z_{k-1} Q_2) -- level_update_t without a second trip of every row through LDS.
+template <int NS, bool IDENT = false, bool UPDATE = false>
 __device__ __forceinline__ void rows_apply_reflectors_t(ldsd *A0, int n0, ldsd *A1, int n1, int ldr, int nr, int ka,
 							int kb, const Lds &l)
 {
@@ -406,14 +429,23 @@ __device__ __forceinline__ void rows_apply_reflectors_t(ldsd *A0, int n0, ldsd *
 		valid[sl] = r < R;
 		const int rr = valid[sl] ? r : 0;
 		rowp[sl] = (rr < n0) ? A0 + rr * ldr : A1 + (rr - n0) * ldr;
-		ld8(x[sl], rowp[sl] + s);
+		if (!IDENT)
+			ld8(x[sl], rowp[sl] + s);
 	}
+	if (IDENT) {
 #pragma unroll
-	for (int sl = 0; sl < NS; ++sl)
-		pin8(x[sl]);
+		for (int sl = 0; sl < NS; ++sl) {
+			const int r = c + 16 * sl;
+			t_upto(nr, s, [&](int t, bool on) { x[sl][t] = (on && valid[sl] && s + 4 * t == r) ? 1.0 : 0.0; });
+		}
+	} else {
 #pragma unroll
-	for (int sl = 0; sl < NS; ++sl)
-		t_upto(nr, s, [&](int t, bool on) { x[sl][t] = sel(on && valid[sl], x[sl][t]); });
+		for (int sl = 0; sl < NS; ++sl)
+			pin8(x[sl]);
+#pragma unroll
+		for (int sl = 0; sl < NS; ++sl)
+			t_upto(nr, s, [&](int t, bool on) { x[sl][t] = sel(on && valid[sl], x[sl][t]); });
+	}
 	for (int k = ka; k < kb; ++k) {
 		const ldsd *vr = VR + k * LDV;
 		double tk = l.tau[k];
@@ -433,6 +465,35 @@ __device__ __forceinline__ void rows_apply_reflectors_t(ldsd *A0, int n0, ldsd *
 			const double d = quad_sum(d0 + d1) * tk;
 			t_from(k, nr, s, [&](int t, bool, bool) { x[sl][t] = fma(-d, vv[t], x[sl][t]); });
 		}
+	}
+	if (UPDATE) {
+		double yv[NT];
+		load8(yv, l.tmp + s);
+		t_upto(nr, s, [&](int t, bool on) { yv[t] = sel(on, yv[t]); });
+#pragma unroll
+		for (int sl = 0; sl < NS; ++sl) {
+			double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+			for (int t = 0; t < NT; ++t) {
+				if (t & 1)
+					d1 = fma(x[sl][t], yv[t], d1);
+				else
+					d0 = fma(x[sl][t], yv[t], d0);
+			}
+			const double d = quad_sum(d0 + d1);
+			if (valid[sl] && s == 0)
+				l.S[c + 16 * sl] = d;
+		}
+		if (kb < nr) {
+#pragma unroll
+			for (int sl = 0; sl < NS; ++sl) {
+				t_from(kb, nr, s, [&](int t, bool on, bool) {
+					st_if(on && valid[sl] && s + 4 * t < nr, rowp[sl] + (s + 4 * t - kb), l.dump + lane, x[sl][t]);
+				});
+			}
+		}
+		wave_sync();
+		return;
 	}
 #pragma unroll
 	for (int sl = 0; sl < NS; ++sl) {
@@ -2215,6 +2276,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 	double dmin_level = 1e300;  // smallest pivot of an unconstrained solve (conditioning estimate)
 
 	int rank = 0;
+	bool updated = false;	 // the level update already happened in the rotation pass
 	double yi = 0.0;	 // lane i holds y_i (rotated coordinates)
 	double res_const = 0.0;	 // part of the level residual that no y can change (tall levels)
 	int mB = m;		 // LS rows seen by the active-set loop
@@ -2582,7 +2644,24 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 		wave_sync();
 		HOQP_STAMP(3);
 		// ---- 3. rotate Z and every stored inequality row: Z <- Z Q, G <- G Q ----
-		if (rank > 0)
+		if (WBC && GATE && !HARD && KC >= 0 && KC != 1) {
+			// a specialised unconstrained level (no stored rows, y final): rotation and level update in one
+			// pass over the rows of Z; at level 0 Z = I has not been written (kernel main) and the rotation
+			// generates its rows
+			if (rank > 0) {
+				wave_sync();
+				l.tmp[lane] = (lane < nz) ? yi : 0.0;
+				wave_sync();
+				if (KC == 0)
+					rows_apply_reflectors_t<2, true, true>(l.Z, n, l.G, 0, ld, nz, 0, rank, l);
+				else
+					rows_apply_reflectors_t<2, false, true>(l.Z, n, l.G, 0, ld, nz, 0, rank, l);
+				updated = true;
+			} else if (KC == 0) {
+				lds_set_identity(l.Z, n, ld);
+				wave_sync();
+			}
+		} else if (rank > 0)
 			rows_apply_reflectors(l.Z, n, l.G, Pg, ld, nz, 0, rank, l);
 		HOQP_STAMP(4);
 	}
@@ -2891,7 +2970,9 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 	wave_sync();
 	{
 		const int R = n + Pg;
-		if (R <= 32)
+		if (updated)
+			;
+		else if (R <= 32)
 			level_update_t<2>(l, n, Pg, nz, rank, ld, HOQP_DBGP);
 		else if (R <= 64)
 			level_update_t<4>(l, n, Pg, nz, rank, ld, HOQP_DBGP);
@@ -3183,21 +3264,10 @@ __global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
 	st.Pout = 0;
 	st.t_last = __builtin_amdgcn_s_memtime();
 	const int n = st.n, ld = a.ld;
-	// InitPrevProblemValuesToDefault, ho_qp_problem.cpp:119-128:  Z = I, x = 0
-	{
-		// (row, column) of entry idx advance by 64 entries per trip without a division per trip
-		const int qstep = kWave / ld, rstep = kWave - qstep * ld;
-		int r = lane / ld, c = lane - r * ld;
-		for (int idx = lane; idx < n * ld; idx += kWave) {
-			l.Z[idx] = (r == c) ? 1.0 : 0.0;
-			r += qstep;
-			c += rstep;
-			if (c >= ld) {
-				c -= ld;
-				++r;
-			}
-		}
-	}
+	// InitPrevProblemValuesToDefault, ho_qp_problem.cpp:119-128:  Z = I, x = 0  (the specialised level 0 of the
+	// fused reference kernel never reads Z = I: its projection is direct and its rotation generates the rows)
+	if (!(WBC && GATE && !HARD))
+		lds_set_identity(l.Z, n, ld);
 	if (lane < NR)
 		l.x[lane] = 0.0;
 	// Touch every cache line of the instance's M, J_foot, h and J_dot u now (one load per lane, one line
