@@ -291,6 +291,9 @@ def main():
         solver.synchronize()
         inp["leg_cmd"], inp["contact"] = lc.cpu().numpy(), ct.cpu().numpy()
     out = solver.alloc_wbc_outputs(nloc)
+    # the per-level intermediate solutions are a diagnostic output (the reference's CalcJointCmd reads the last
+    # problem's solution only, ho_qp_controller.cpp:13-16): not requested on the benchmarked path
+    out["x_levels"] = None
     if args.skip_unread_slack:
         out["v"] = None
 
@@ -349,8 +352,9 @@ def main():
         streams = [torch.cuda.Stream() for _ in range(ns)]
         solvers = [hoqp.HoQpSolver(solver.cfg) for _ in range(ns)]
         outs = [solver.alloc_wbc_outputs(nloc) for _ in range(ns)]
-        if args.skip_unread_slack:
-            for o in outs:
+        for o in outs:
+            o["x_levels"] = None
+            if args.skip_unread_slack:
                 o["v"] = None
         torch.cuda.synchronize()
         reps = max(args.steps, 20)

@@ -261,7 +261,9 @@ __device__ __forceinline__ void t_upto(int nr, int s, Body body)
 	} while (0)
 #endif
 
-template <int NS>
+// NTA: register blocks of four entries that can be non-zero (vector length nr <= 4 NTA): the loops over a
+// vector's registers stop there -- at the tracking level of the WBC (n_z = 12) that is 3 of 8.
+template <int NS, int NTA>
 __device__ __forceinline__ int panel_factor_t(double (&x)[NSP][NT], int (&pos)[NSP], int qlo, int qhi, int nr, int k0,
 					      double rtol, const Lds &l, unsigned long long *dbgp)
 {
@@ -279,13 +281,14 @@ __device__ __forceinline__ int panel_factor_t(double (&x)[NSP][NT], int (&pos)[N
 #pragma unroll
 		for (int sl = 0; sl < NS; ++sl) {
 			double a0 = 0.0, a1 = 0.0;
-			t_from(k, nr, s, [&](int t, bool on, bool) {
-				const double v = on ? x[sl][t] : 0.0;
+#pragma unroll
+			for (int t = 0; t < NTA; ++t) {
+				const double v = (s + 4 * t >= k) ? x[sl][t] : 0.0;
 				if (t & 1)
 					a1 = fma(v, v, a1);
 				else
 					a0 = fma(v, v, a0);
-			});
+			}
 			const double ss = quad_sum(a0 + a1);
 			const int q = c + 16 * sl;
 			const bool mine = pos[sl] == -1 && q >= qlo && q < qhi;
@@ -319,6 +322,7 @@ __device__ __forceinline__ int panel_factor_t(double (&x)[NSP][NT], int (&pos)[N
 			for (int sl = 0; sl < NS; ++sl) {
 				if (NS > 1 && sl != ps)
 					continue;
+				// the whole row of the store is written (zeros beyond nr): its readers take full rows
 				t_upto(nr, s, [&](int t, bool) { vr[s + 4 * t] = x[sl][t]; });
 				pos[sl] = k;
 			}
@@ -326,29 +330,38 @@ __device__ __forceinline__ int panel_factor_t(double (&x)[NSP][NT], int (&pos)[N
 		wave_sync();
 		double alpha = vr[k];
 		double vv[NT];
-		load8(vv, vr + s);
+#pragma unroll
+		for (int t = 0; t < NTA; ++t)
+			vv[t] = vr[s + 4 * t];
 		pin(alpha);
+#pragma unroll
+		for (int t = 0; t < NTA; ++t)
+			pin(vv[t]);
 		PF_T(3);
 		const double beta = (alpha >= 0.0) ? -nrm : nrm;
 		const double v0 = alpha - beta;
 		const double tk = rn * fast_rcp(nrm + fabs(alpha));  // 2 / v'v = 1 / (nrm (nrm + |alpha|))
-		t_from(k, nr, s, [&](int t, bool on, bool) {
+#pragma unroll
+		for (int t = 0; t < NTA; ++t) {
 			const double u = (s + 4 * t == k) ? v0 : vv[t];
-			vv[t] = on ? u : 0.0;
-		});
+			vv[t] = (s + 4 * t >= k) ? u : 0.0;
+		}
 		PF_T(4);
 #pragma unroll
 		for (int sl = 0; sl < NS; ++sl) {
 			double d0 = 0.0, d1 = 0.0;
-			t_from(k, nr, s, [&](int t, bool, bool) {
+#pragma unroll
+			for (int t = 0; t < NTA; ++t) {
 				if (t & 1)
 					d1 = fma(vv[t], x[sl][t], d1);
 				else
 					d0 = fma(vv[t], x[sl][t], d0);
-			});
+			}
 			double d = quad_sum(d0 + d1) * tk;
 			d = (pos[sl] == -1) ? d : 0.0;
-			t_from(k, nr, s, [&](int t, bool, bool) { x[sl][t] = fma(-d, vv[t], x[sl][t]); });
+#pragma unroll
+			for (int t = 0; t < NTA; ++t)
+				x[sl][t] = fma(-d, vv[t], x[sl][t]);
 		}
 		if (lane == 0) {
 			vr[k] = v0;  // program order: after every lane's read of vr[k] above
@@ -371,16 +384,31 @@ __device__ __forceinline__ int panel_factor_t(double (&x)[NSP][NT], int (&pos)[N
 	return k;
 }
 
-// slot count fixed at compile time inside the step loop (a per-slot scalar branch in every
-// step cost more than the slot's arithmetic); one dispatch per factorization
+// slot count and vector length class fixed at compile time inside the step loop (a per-slot scalar branch in
+// every step cost more than the slot's arithmetic); one dispatch per factorization
+// VL: dispatch on the vector length class as well (the specialised level copies of the fused reference kernel;
+// in the general kernels the three extra copies of every step cost more than they save: paper semantics
+// 5.2 -> 4.4 M solves/s)
+template <int NS, bool VL>
+__device__ __forceinline__ int panel_factor_n(double (&x)[NSP][NT], int (&pos)[NSP], int qlo, int qhi, int nr, int k0,
+					      double rtol, const Lds &l, unsigned long long *dbgp)
+{
+	if (VL && nr <= 12)
+		return panel_factor_t<NS, 3>(x, pos, qlo, qhi, nr, k0, rtol, l, dbgp);
+	if (VL && nr <= 24)
+		return panel_factor_t<NS, 6>(x, pos, qlo, qhi, nr, k0, rtol, l, dbgp);
+	return panel_factor_t<NS, NT>(x, pos, qlo, qhi, nr, k0, rtol, l, dbgp);
+}
+
+template <bool VL = false>
 __device__ __forceinline__ int panel_factor(double (&x)[NSP][NT], int (&pos)[NSP], int nslot, int qlo, int qhi, int nr, int k0,
 				   double rtol, const Lds &l, unsigned long long *dbgp = nullptr)
 {
 	if (nslot <= 1)
-		return panel_factor_t<1>(x, pos, qlo, qhi, nr, k0, rtol, l, dbgp);
+		return panel_factor_n<1, VL>(x, pos, qlo, qhi, nr, k0, rtol, l, dbgp);
 	if (nslot == 2)
-		return panel_factor_t<2>(x, pos, qlo, qhi, nr, k0, rtol, l, dbgp);
-	return panel_factor_t<NSP>(x, pos, qlo, qhi, nr, k0, rtol, l, dbgp);
+		return panel_factor_n<2, VL>(x, pos, qlo, qhi, nr, k0, rtol, l, dbgp);
+	return panel_factor_n<NSP, VL>(x, pos, qlo, qhi, nr, k0, rtol, l, dbgp);
 }
 
 // Z = I (n x n, leading dimension ld): InitPrevProblemValuesToDefault, ho_qp_problem.cpp:119-128
@@ -1520,7 +1548,7 @@ __device__ __forceinline__ int unp_index(bool unp, int &base)
 //   [ G_W' | B0' | G_V' ]  (w + m + |V| <= 64 columns, rows of V listed in l.vlist).
 // Returns p_i in lane i; *k1_out = rank of the working set (reflectors [0,k1) stay in TV).
 // ---------------------------------------------------------------------------
-template <bool HARD>
+template <bool HARD, bool VL = false>
 __device__ __forceinline__ double eqp_step(const SolveArgs &a, const Lds &l, LevelState &st, int nz, int rank, int m, int w_in,
 				  int nV, int *k1_out, bool *overflow)
 {
@@ -1573,9 +1601,9 @@ __device__ __forceinline__ double eqp_step(const SolveArgs &a, const Lds &l, Lev
 		l.colpos[lane] = -1;
 	}
 	wave_sync();
-	const int k1 = HARD ? uni(panel_factor(x, pos, nslot, 0, w, nz, 0, 1e-12, l)) : 0;
+	const int k1 = HARD ? uni(panel_factor<VL>(x, pos, nslot, 0, w, nz, 0, 1e-12, l)) : 0;
 	HOQP_STAMP(8);
-	const int k2 = uni(panel_factor(x, pos, nslot, w, ncol, nz, k1, 1e-11, l));
+	const int k2 = uni(panel_factor<VL>(x, pos, nslot, w, ncol, nz, k1, 1e-11, l));
 	HOQP_STAMP(9);
 	*k1_out = k1;
 	// unpivoted B columns -> X
@@ -2466,7 +2494,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 				t_upto(m, s, [&](int t, bool on) { x[sl][t] = sel(on && pos[sl] == -1, x[sl][t]); });
 			}
 			wave_sync();
-			const int rT = uni(panel_factor(x, pos, nslot, 0, nz, m, 0, kEpsMach * (double)max(m, nz), l, HOQP_DBGP));
+			const int rT = uni(panel_factor<(WBC && GATE && !HARD && KC >= 0)>(x, pos, nslot, 0, nz, m, 0, kEpsMach * (double)max(m, nz), l, HOQP_DBGP));
 			HOQP_STAMP(2);
 			if (rT < nz) {
 				tall = false;  // rank-deficient: project again, then the general path
@@ -2575,7 +2603,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 			t_upto(nz, s, [&](int t, bool on) { x[sl][t] = sel(on && pos[sl] == -1, x[sl][t]); });
 		}
 		wave_sync();  // every column is in registers before TV is reused as the reflector store
-		rank = uni(panel_factor(x, pos, nslot, 0, m, nz, 0, kEpsMach * (double)max(m, nz), l, HOQP_DBGP));
+		rank = uni(panel_factor<(WBC && GATE && !HARD && KC >= 0)>(x, pos, nslot, 0, m, nz, 0, kEpsMach * (double)max(m, nz), l, HOQP_DBGP));
 		HOQP_STAMP(2);
 		int nunp = 0;
 		int uidx[NSP];
@@ -2790,7 +2818,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 						a.dbg[(size_t)blockIdx.x * kDbgSlots + 50] += 1;  // steps through the small side
 #endif
 				} else
-				pi = eqp_step<HARD>(a, l, st, nz, rank, mB, w, nV, &k1, &overflow);
+				pi = eqp_step<HARD, (WBC && GATE && !HARD && KC >= 0)>(a, l, st, nz, rank, mB, w, nV, &k1, &overflow);
 				if (overflow) {
 					st.status |= HOQP_STATUS_WORKSPACE;
 					break;
