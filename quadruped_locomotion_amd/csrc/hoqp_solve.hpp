@@ -437,7 +437,8 @@ __device__ __forceinline__ void lds_set_identity(ldsd *Z, int n, int ld)
 // UPDATE: the level update in the same pass (the level's y, rotated coordinates, is already in l.tmp): after
 // the rotation the row is still in registers, so d_r = row_r . y -> l.S[r] and the row is stored without its
 // first kb coordinates (Z_k = Z_{k-1} Q_2) -- level_update_t without a second trip of every row through LDS.
-template <int NS, bool IDENT = false, bool UPDATE = false>
+// NTA: register blocks of four entries that can be non-zero (nr <= 4 NTA), as in panel_factor_t.
+template <int NS, bool IDENT = false, bool UPDATE = false, int NTA = NT>
 __device__ __forceinline__ void rows_apply_reflectors_t(ldsd *A0, int n0, ldsd *A1, int n1, int ldr, int nr, int ka,
 							int kb, const Lds &l)
 {
@@ -457,52 +458,80 @@ __device__ __forceinline__ void rows_apply_reflectors_t(ldsd *A0, int n0, ldsd *
 		valid[sl] = r < R;
 		const int rr = valid[sl] ? r : 0;
 		rowp[sl] = (rr < n0) ? A0 + rr * ldr : A1 + (rr - n0) * ldr;
-		if (!IDENT)
-			ld8(x[sl], rowp[sl] + s);
+		if (!IDENT) {
+#pragma unroll
+			for (int t = 0; t < NTA; ++t)
+				x[sl][t] = rowp[sl][s + 4 * t];
+		}
 	}
 	if (IDENT) {
 #pragma unroll
 		for (int sl = 0; sl < NS; ++sl) {
 			const int r = c + 16 * sl;
-			t_upto(nr, s, [&](int t, bool on) { x[sl][t] = (on && valid[sl] && s + 4 * t == r) ? 1.0 : 0.0; });
+#pragma unroll
+			for (int t = 0; t < NTA; ++t)
+				x[sl][t] = (s + 4 * t < nr && valid[sl] && s + 4 * t == r) ? 1.0 : 0.0;
 		}
 	} else {
 #pragma unroll
-		for (int sl = 0; sl < NS; ++sl)
-			pin8(x[sl]);
+		for (int sl = 0; sl < NS; ++sl) {
 #pragma unroll
-		for (int sl = 0; sl < NS; ++sl)
-			t_upto(nr, s, [&](int t, bool on) { x[sl][t] = sel(on && valid[sl], x[sl][t]); });
+			for (int t = 0; t < NTA; ++t)
+				pin(x[sl][t]);
+		}
+#pragma unroll
+		for (int sl = 0; sl < NS; ++sl) {
+#pragma unroll
+			for (int t = 0; t < NTA; ++t)
+				x[sl][t] = sel(s + 4 * t < nr && valid[sl], x[sl][t]);
+		}
 	}
 	for (int k = ka; k < kb; ++k) {
 		const ldsd *vr = VR + k * LDV;
 		double tk = l.tau[k];
 		double vv[NT];
-		load8(vv, vr + s);
+#pragma unroll
+		for (int t = 0; t < NTA; ++t)
+			vv[t] = vr[s + 4 * t];
 		pin(tk);
-		t_from(k, nr, s, [&](int t, bool on, bool) { vv[t] = sel(on, vv[t]); });
+#pragma unroll
+		for (int t = 0; t < NTA; ++t)
+			pin(vv[t]);
+#pragma unroll
+		for (int t = 0; t < NTA; ++t)
+			vv[t] = sel(s + 4 * t >= k, vv[t]);
 #pragma unroll
 		for (int sl = 0; sl < NS; ++sl) {
 			double d0 = 0.0, d1 = 0.0;
-			t_from(k, nr, s, [&](int t, bool, bool) {
+#pragma unroll
+			for (int t = 0; t < NTA; ++t) {
 				if (t & 1)
 					d1 = fma(vv[t], x[sl][t], d1);
 				else
 					d0 = fma(vv[t], x[sl][t], d0);
-			});
+			}
 			const double d = quad_sum(d0 + d1) * tk;
-			t_from(k, nr, s, [&](int t, bool, bool) { x[sl][t] = fma(-d, vv[t], x[sl][t]); });
+#pragma unroll
+			for (int t = 0; t < NTA; ++t)
+				x[sl][t] = fma(-d, vv[t], x[sl][t]);
 		}
 	}
 	if (UPDATE) {
 		double yv[NT];
-		load8(yv, l.tmp + s);
-		t_upto(nr, s, [&](int t, bool on) { yv[t] = sel(on, yv[t]); });
+#pragma unroll
+		for (int t = 0; t < NTA; ++t)
+			yv[t] = l.tmp[s + 4 * t];
+#pragma unroll
+		for (int t = 0; t < NTA; ++t)
+			pin(yv[t]);
+#pragma unroll
+		for (int t = 0; t < NTA; ++t)
+			yv[t] = sel(s + 4 * t < nr, yv[t]);
 #pragma unroll
 		for (int sl = 0; sl < NS; ++sl) {
 			double d0 = 0.0, d1 = 0.0;
 #pragma unroll
-			for (int t = 0; t < NT; ++t) {
+			for (int t = 0; t < NTA; ++t) {
 				if (t & 1)
 					d1 = fma(x[sl][t], yv[t], d1);
 				else
@@ -515,9 +544,11 @@ __device__ __forceinline__ void rows_apply_reflectors_t(ldsd *A0, int n0, ldsd *
 		if (kb < nr) {
 #pragma unroll
 			for (int sl = 0; sl < NS; ++sl) {
-				t_from(kb, nr, s, [&](int t, bool on, bool) {
-					st_if(on && valid[sl] && s + 4 * t < nr, rowp[sl] + (s + 4 * t - kb), l.dump + lane, x[sl][t]);
-				});
+#pragma unroll
+				for (int t = 0; t < NTA; ++t) {
+					const int i = s + 4 * t;
+					st_if(i >= kb && i < nr && valid[sl], rowp[sl] + (i - kb), l.dump + lane, x[sl][t]);
+				}
 			}
 		}
 		wave_sync();
@@ -525,7 +556,9 @@ __device__ __forceinline__ void rows_apply_reflectors_t(ldsd *A0, int n0, ldsd *
 	}
 #pragma unroll
 	for (int sl = 0; sl < NS; ++sl) {
-		t_upto(nr, s, [&](int t, bool on) { st_if(on && valid[sl], rowp[sl] + (s + 4 * t), l.dump + lane, x[sl][t]); });
+#pragma unroll
+		for (int t = 0; t < NTA; ++t)
+			st_if(s + 4 * t < nr && valid[sl], rowp[sl] + (s + 4 * t), l.dump + lane, x[sl][t]);
 	}
 	wave_sync();
 }
@@ -2682,6 +2715,10 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 				wave_sync();
 				if (KC == 0)
 					rows_apply_reflectors_t<2, true, true>(l.Z, n, l.G, 0, ld, nz, 0, rank, l);
+				else if (nz <= 12)
+					rows_apply_reflectors_t<2, false, true, 3>(l.Z, n, l.G, 0, ld, nz, 0, rank, l);
+				else if (nz <= 24)
+					rows_apply_reflectors_t<2, false, true, 6>(l.Z, n, l.G, 0, ld, nz, 0, rank, l);
 				else
 					rows_apply_reflectors_t<2, false, true>(l.Z, n, l.G, 0, ld, nz, 0, rank, l);
 				updated = true;
