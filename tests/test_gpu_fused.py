@@ -242,3 +242,23 @@ def test_host_entry_batched(solver_factory):
         for key in ("x", "qdd", "tau", "v", "flags", "level_res", "eq_res_max", "ineq_viol_max", "iters", "nz_levels", "status"):
             assert np.array_equal(h[key], d[key]), key
         assert np.array_equal(h["active_mask"], d["active_mask"].astype(np.uint64))
+
+
+def test_contact_flags_that_are_neither_contact_nor_swing(solver_factory, oracle):
+    """GetContactLegs / GetSwingLegs (ho_qp_controller.cpp:426-450) compare the contact pattern with 1 and with
+    0: a leg whose flag is anything else is in neither list (n_c + n_s < 4).  The specialised kernel's shape
+    facts (n = 18 + 3 n_c, row counts) must hold for such states too: results against the oracle."""
+    s = solver_factory("reference")
+    st = am.sample_states(24, 31, "stance")
+    pats = np.array([(1, 2, 1, 1), (1, 1, -1, 0), (2, 2, 2, 2), (1, 0, 3, 1)], dtype=np.int32)
+    st["contact"] = np.repeat(pats, 6, axis=0)
+    inp = am.make_wbc_inputs(st)
+    out = {k: v.cpu().numpy() for k, v in s.solve_wbc(s.to_device(inp)).items()}
+    s.synchronize()
+    ref, rc = oracle.wbc_solve_batch(inp)
+    assert rc == 0 and np.all(out["status"] == 0) and np.all(ref["status"] == 0)
+    for key in ("x", "qdd", "tau", "v"):
+        assert np.all(np.isfinite(out[key])), key
+        r = ref[key][:, :out[key].shape[1]]
+        assert np.all(np.abs(out[key] - r) <= 1e-6 * np.maximum(1.0, np.abs(r))), key
+    assert np.array_equal(out["nz_levels"][:, :4], ref["nz_levels"][:, :4])
