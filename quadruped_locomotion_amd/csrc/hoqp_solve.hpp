@@ -2774,8 +2774,10 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 			level_res2 = 0.0;
 		}
 	}
+	bool qp_ran = false;
 	if (consider && !skip_qp) {
 		// ---- 4b. primal active set on the piecewise quadratic ----
+		qp_ran = true;
 		if (lane < Pn)
 			l.s[lane] = -l.g[lane];
 		if (lane < mB)
@@ -3034,15 +3036,20 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 	l.tmp[lane] = (lane < nz) ? yi : 0.0;
 	wave_sync();
 	{
-		const int R = n + Pg;
+		// After the active-set loop l.s holds G y - g for every row (it moved with y, step by step), so the
+		// products G y need not be formed again; with rank == 0 the stored rows are not shifted either, and
+		// the update visits the rows of Z only (the all-soft level of the WBC: 30 rows instead of 70).
+		const bool from_s = qp_ran && rank == 0;
+		const int Pu = from_s ? 0 : Pg;
+		const int R = n + Pu;
 		if (updated)
 			;
 		else if (R <= 32)
-			level_update_t<2>(l, n, Pg, nz, rank, ld, HOQP_DBGP);
+			level_update_t<2>(l, n, Pu, nz, rank, ld, HOQP_DBGP);
 		else if (R <= 64)
-			level_update_t<4>(l, n, Pg, nz, rank, ld, HOQP_DBGP);
+			level_update_t<4>(l, n, Pu, nz, rank, ld, HOQP_DBGP);
 		else
-			level_update_t<NSR>(l, n, Pg, nz, rank, ld, HOQP_DBGP);
+			level_update_t<NSR>(l, n, Pu, nz, rank, ld, HOQP_DBGP);
 		wave_sync();
 		HOQP_STAMP(27);
 		// one row per lane: x += (Z y), g -= (G y) with the slack bookkeeping of this level's rows
@@ -3051,7 +3058,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 		bool nonfinite = !isfinite(level_res2);
 		const double dq = q3 ? q3_delta() : 0.0;  // stored g goes back to each row's own slack
 		if (lane < Pg) {
-			double gi = l.g[lane] - l.S[n + lane] - dq;
+			double gi = (from_s ? 0.0 - l.s[lane] : l.g[lane] - l.S[n + lane]) - dq;
 			if (lane >= P) {
 				// v* = (D x - f)_+ ; the row becomes hard with rhs f + v* - D x
 				const double vopt = fmax(0.0, -gi);
