@@ -49,6 +49,9 @@ extern "C" {
 #define HOQP_STATUS_NONFINITE 0x08	 /* NaN/Inf in the final x, a slack, a level residual, a validity residual or tau */
 #define HOQP_STATUS_UNSUPPORTED 0x10	 /* (unused since Q3 is reproduced for any number of inequality levels) */
 #define HOQP_STATUS_BAD_EXTENT 0x20	 /* n_inst / m_inst / p_inst beyond the storage extent: clamped to it */
+#define HOQP_STATUS_BASE_RANK 0x40	 /* hoqp_solve_wbc_batched, reference semantics: [M_fb, -J_c,fb^T] (the floating-base
+					  * block of ho_qp_controller.cpp:351-366) has rank < 6 -- not a physical mass matrix.
+					  * The state is not solved (x, tau, slacks = NaN); hoqp_solve_wbc_unfused takes any state */
 
 typedef struct hoqp_handle hoqp_handle;
 
@@ -70,7 +73,10 @@ typedef struct {
  * the hierarchy ends with an empty null space (the WBC hierarchy) the final x, tau and validity flags are
  * the same to ~1e-7 relative (the eps_ bias of the later levels depends on where in that null space x sits),
  * while x_levels of the skipped level keep the previous level's x.  In the
- * reference's WBC hierarchy this removes the torque / friction level's QP (about 30 % of the solve). */
+ * reference's WBC hierarchy this removes the torque / friction level's QP (about 30 % of the solve).
+ * Honoured by hoqp_solve_wbc_batched / hoqp_solve_wbc_host only: a generic hierarchy
+ * (hoqp_solve_tasks_batched, and the unfused / allocation-free WBC entries built on it) need not end with an
+ * empty null space, so the option is ignored there. */
 #define HOQP_OPT_SKIP_UNREAD_SLACK_LEVELS 0x01
 
 /* Replaces: the compile-time constants of HoQpController / HoQpProblem. */

@@ -12,6 +12,8 @@
 // ho_qp_problem.cpp:180-285 with xi = [z; v]; the redundant rows -v <= 0 are implied.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -222,7 +224,10 @@ constexpr size_t kScratchBytes = (size_t)HOQP_NOALLOC_MAX_BATCH * (kTaskDoubles 
 constexpr int kMaxDevices = 64;
 }  // namespace
 static __device__ __align__(256) unsigned char scratch[kScratchBytes];
-static void *g_scratch_ptr[kMaxDevices];  // device address of `scratch` on each GPU (null: not taken yet)
+// device address of `scratch` on each GPU (null: not taken yet).  Atomic: hoqp_create may run on several host
+// threads at once (one handle per thread); every thread that finds null asks the runtime and publishes the same value.
+static std::atomic<void *> g_scratch_ptr[kMaxDevices];
+constexpr size_t kEvRing = 256;  // timing: event pairs in flight per handle (older ones are folded into the sums)
 
 struct hoqp_handle {
 	hoqp_config cfg;
@@ -236,10 +241,31 @@ struct hoqp_handle {
 	int ws_batch = 0;
 	double *ws_d = nullptr;
 	int *ws_i = nullptr;
-	// kernel timing
+	// kernel timing: a ring of kEvRing event pairs, created on first use and reused; completed pairs are folded
+	// into (ev_ms, ev_cnt), so a caller that leaves timing on for days holds 2 * kEvRing events, not one per launch
 	bool timing = false;
-	std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> ev = std::vector<std::pair<hipEvent_t, hipEvent_t>>(kEvRing, {nullptr, nullptr});
+	size_t ev_head = 0, ev_live = 0;
+	double ev_ms = 0.0;
+	long long ev_cnt = 0;
 };
+
+// oldest live event pair -> sums (waits for it if the GPU is more than kEvRing launches behind)
+static hipError_t fold_oldest_event(hoqp_handle *h)
+{
+	auto &e = h->ev[h->ev_head];
+	float ms = 0.f;
+	hipError_t rc = hipEventSynchronize(e.second);
+	if (rc == hipSuccess)
+		rc = hipEventElapsedTime(&ms, e.first, e.second);
+	if (rc == hipSuccess) {
+		h->ev_ms += ms;
+		++h->ev_cnt;
+	}
+	h->ev_head = (h->ev_head + 1) % kEvRing;
+	--h->ev_live;
+	return rc;
+}
 
 static int fail(hoqp_handle *h, int code, const std::string &msg)
 {
@@ -310,15 +336,15 @@ extern "C" int hoqp_create(const hoqp_config *cfg, hoqp_handle **out)
 		lds = 65536;
 	h->max_lds = lds;
 	// device address of the scratch array on THIS device (each GPU holds its own copy at its own address)
-	if (!g_scratch_ptr[cfg->device]) {
-		void *p = nullptr;
-		if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) {
+	void *sp = g_scratch_ptr[cfg->device].load(std::memory_order_acquire);
+	if (!sp) {
+		if (hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch)) != hipSuccess || !sp) {
 			delete h;
 			return -3;
 		}
-		g_scratch_ptr[cfg->device] = p;
+		g_scratch_ptr[cfg->device].store(sp, std::memory_order_release);
 	}
-	h->scratch_ptr = g_scratch_ptr[cfg->device];
+	h->scratch_ptr = sp;
 	*out = h;
 	return 0;
 }
@@ -329,8 +355,10 @@ extern "C" int hoqp_destroy(hoqp_handle *h)
 		return -1;
 	DeviceScope scope(h->cfg.device);
 	for (auto &e : h->ev) {
-		(void)hipEventDestroy(e.first);
-		(void)hipEventDestroy(e.second);
+		if (e.first)
+			(void)hipEventDestroy(e.first);
+		if (e.second)
+			(void)hipEventDestroy(e.second);
 	}
 	if (h->ws_d)
 		(void)hipFree(h->ws_d);
@@ -411,6 +439,10 @@ static int fill_args(hoqp_handle *h, const hoqp_task_batch *t, const hoqp_result
 	a->p_inst = t->p_inst;
 	a->out = *out;
 	fill_common(h, a);
+	// HOQP_OPT_SKIP_UNREAD_SLACK_LEVELS is an option of the fused WBC entry, whose hierarchy ends with an empty
+	// null space (the skipped level can then not change the final x).  A generic hierarchy gives no such
+	// guarantee, so the option is not honoured here.
+	a->skip_unread = 0;
 	return 0;
 }
 
@@ -440,7 +472,7 @@ static int launch_solve(hoqp_handle *h, SolveArgs &a, hipStream_t s, bool wbc, b
 #ifdef HOQP_PROFILE
 	// profiling build: per-section cycle stamps of one launch, printed to stderr
 	unsigned long long *dbg = nullptr;
-	if (getenv("HOQP_DBG") && a.batch > 0) {
+	if (timed && getenv("HOQP_DBG") && a.batch > 0) {  // never on the allocation-free entry
 		HIP_OK(h, hipMalloc(&dbg, sizeof(unsigned long long) * kDbgSlots * a.batch));
 		HIP_OK(h, hipMemset(dbg, 0, sizeof(unsigned long long) * kDbgSlots * a.batch));
 	}
@@ -493,6 +525,8 @@ static int launch_solve(hoqp_handle *h, SolveArgs &a, hipStream_t s, bool wbc, b
 	a.dbg = nullptr;
 #endif
 	a.ld = lds_leading_dim(a.n);
+	// the fused WBC entry under reference semantics runs hoqp_solve_wbc_ref_kernel on the compact LDS layout
+	a.compact = (wbc && !a.any_hard) ? 1 : 0;
 	size_t lds = (size_t)lds_offsets(a).total;
 	if ((int)lds > h->max_lds)
 		return fail(h, -5, "LDS workspace " + std::to_string(lds) + " B exceeds the device limit");
@@ -501,7 +535,7 @@ static int launch_solve(hoqp_handle *h, SolveArgs &a, hipStream_t s, bool wbc, b
 	// it is either <gated, no hard rows> or <ungated, hard rows>
 	void (*kern)(const SolveArgs);
 	if (wbc)
-		kern = !a.any_hard ? hoqp_solve_kernel<true, false, true> : hoqp_solve_kernel<false, true, true>;
+		kern = !a.any_hard ? hoqp_solve_wbc_ref_kernel : hoqp_solve_kernel<false, true, true>;
 	else
 		kern = !a.any_hard ? hoqp_solve_kernel<true, false, false>
 				   : (a.gate_prior ? hoqp_solve_kernel<true, true, false> : hoqp_solve_kernel<false, true, false>);
@@ -511,17 +545,22 @@ static int launch_solve(hoqp_handle *h, SolveArgs &a, hipStream_t s, bool wbc, b
 		HIP_OK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 	if (a.batch == 0)
 		return 0;
-	hipEvent_t e0 = nullptr, e1 = nullptr;
-	if (timed && h->timing && h->ev.size() < 100000) {
-		HIP_OK(h, hipEventCreate(&e0));
-		HIP_OK(h, hipEventCreate(&e1));
-		HIP_OK(h, hipEventRecord(e0, s));
+	std::pair<hipEvent_t, hipEvent_t> *slot = nullptr;
+	if (timed && h->timing) {
+		if (h->ev_live == kEvRing)
+			HIP_OK(h, fold_oldest_event(h));
+		slot = &h->ev[(h->ev_head + h->ev_live) % kEvRing];
+		if (!slot->first)
+			HIP_OK(h, hipEventCreate(&slot->first));
+		if (!slot->second)
+			HIP_OK(h, hipEventCreate(&slot->second));
+		HIP_OK(h, hipEventRecord(slot->first, s));
 	}
 	hipLaunchKernelGGL(kern, dim3(a.batch), dim3(kWave), lds, s, a);
 	HIP_OK(h, hipGetLastError());
-	if (e0) {
-		HIP_OK(h, hipEventRecord(e1, s));
-		h->ev.emplace_back(e0, e1);
+	if (slot) {
+		HIP_OK(h, hipEventRecord(slot->second, s));
+		++h->ev_live;
 	}
 	return 0;
 }
@@ -1230,25 +1269,15 @@ extern "C" int hoqp_kernel_time_ms(hoqp_handle *h, int reset, double *avg_ms, in
 	if (!h)
 		return -1;
 	ENTER_DEVICE(h);
-	double tot = 0.0;
-	int cnt = 0;
-	for (auto &e : h->ev) {
-		float ms = 0.f;
-		HIP_OK(h, hipEventSynchronize(e.second));
-		HIP_OK(h, hipEventElapsedTime(&ms, e.first, e.second));
-		tot += ms;
-		++cnt;
-	}
+	while (h->ev_live > 0)
+		HIP_OK(h, fold_oldest_event(h));
 	if (avg_ms)
-		*avg_ms = cnt ? tot / cnt : 0.0;
+		*avg_ms = h->ev_cnt ? h->ev_ms / (double)h->ev_cnt : 0.0;
 	if (launches)
-		*launches = cnt;
+		*launches = (int)std::min<long long>(h->ev_cnt, 2147483647LL);
 	if (reset) {
-		for (auto &e : h->ev) {
-			(void)hipEventDestroy(e.first);
-			(void)hipEventDestroy(e.second);
-		}
-		h->ev.clear();
+		h->ev_ms = 0.0;  // the event pairs stay in the ring for reuse
+		h->ev_cnt = 0;
 		h->timing = (reset == 1);
 	}
 	return 0;

@@ -26,6 +26,20 @@ constexpr int LDV = 34;	  // leading dimension of the reflector store
 constexpr int SROW = 36;  // row stride of the task staging buffer of the n_z == 32 projection (16-byte
 			  // aligned rows); the matrix-core projection loads its operand from global memory
 constexpr int XROWS = 16; // dumped unpivoted columns (rank-deficient least squares); aliases S
+// Compact LDS layout of the fused WBC kernel under reference semantics (SolveArgs::compact; 26,344 B per
+// workgroup: six workgroups per CU instead of four).  It rests on two facts of that hierarchy: level 0 never
+// stores Z = I (its rotation generates the rows) and leaves n - 6 <= 24 free coordinates, so from level 1 on
+// every vector handled has at most 24 entries -- Z, G, the dependent-column store and the projected task rows
+// take a leading dimension of 25, the reflector store 25 (level 0, whose six reflectors have 30 entries: 34);
+// and at most 8 dependent columns are kept for a rank-deficient least squares (more: HOQP_STATUS_WORKSPACE).
+// A state whose floating-base block [M_fb, -J_c,fb^T] has rank < 6 (impossible for a physical mass matrix) does
+// not fit and is reported as HOQP_STATUS_BASE_RANK instead of being solved.
+constexpr int kCLd = 25;	 // Z, G, X, projected rows of levels >= 1
+constexpr int kCLd0 = 31;	 // projected rows of level 0 (6 x n)
+constexpr int kCLdv = 25;	 // reflector store, levels >= 1
+constexpr int kCXrows = 8;	 // dependent-column store
+constexpr int kCTv = 24 * kCLdv + 8;	 // >= 6 * LDV, >= 18 * kCLd: reflector store / projected rows
+constexpr int kCReplayZ = 1100;	 // replay: doubles for the chain of bases (30 x 24 + 30 x 12), rest: M and K
 constexpr int CHUNK = 16; // task rows per projection pass (one 16 x K matrix-core operand tile)
 constexpr int kDbgSlots = 56;	  // HOQP_PROFILE builds: cycle-stamp slots per instance
 // the reference replay runs when eps / (smallest pivot)^2 of an unconstrained level exceeds this
@@ -47,6 +61,7 @@ struct SolveArgs {
 	int mmax;  // max_k m[k] (<= 32)
 	int ld;	   // odd leading dimension >= n of Z, G, BL, X
 	int use_bl;	   // some level needs its equality rows inside the active-set loop
+	int compact;	   // compact LDS layout (fused WBC entry under reference semantics only)
 	int any_hard;	   // some level looks at rows stored by an earlier level
 	int last_ineq_use; // last level that looks at stored inequality rows (rows are dropped after it)
 	// fused WBC entry (hoqp_solve_kernel<.., .., true>): the task blocks are generated from the
@@ -82,17 +97,26 @@ __host__ __device__ inline LdsOff lds_offsets(const SolveArgs &a)
 		off += (bytes + 15) & ~15;
 		return p;
 	};
-	const int n = a.n, ld = a.ld, P = a.Ptot, mm = a.mmax;
+	const int n = a.n, ld = a.compact ? kCLd : a.ld, P = a.Ptot, mm = a.mmax;
 	const int tv = (LDV * n > ld * mm) ? LDV * n : ld * mm;
 	o.Z = take(8 * n * ld);
 	o.x = take(8 * NR);
-	o.G = take(8 * (P ? P : 1) * ld);
+	if (a.compact) {
+		// G, TV and S are contiguous: the reference replay uses them as one scratch region, and reads
+		// of a masked-off tail of a TV row (tall levels: 32 rows x ld) stay inside the allocation
+		o.G = take(8 * P * ld);
+		o.TV = take(8 * kCTv);
+		o.S = take(8 * kCXrows * ld);
+	}
 	o.g = take(8 * (P + 1));
 	o.vs = take(8 * (P + 1));  // optimal slack v* of every stored inequality row (Q3)
 	o.s = take(8 * (P + 1));
 	o.c = take(8 * (P + 1));
-	o.TV = take(8 * tv);
-	o.S = take(8 * ((CHUNK * SROW > XROWS * ld) ? CHUNK * SROW : XROWS * ld));
+	if (!a.compact) {
+		o.G = take(8 * (P ? P : 1) * ld);
+		o.TV = take(8 * tv);
+		o.S = take(8 * ((CHUNK * SROW > XROWS * ld) ? CHUNK * SROW : XROWS * ld));
+	}
 	o.BL = take(8 * ((mm && a.use_bl) ? mm : 1) * ld);
 	o.r0 = take(8 * (mm + 1));
 	o.rho = take(8 * (mm + 1));
@@ -106,7 +130,7 @@ __host__ __device__ inline LdsOff lds_offsets(const SolveArgs &a)
 	o.b3 = take(8 * 24);	   // fused WBC entry: right-hand side of the tracking level
 	o.pivlane = take(4 * NR);
 	o.W = take(4 * NR);
-	o.xlane = take(4 * XROWS);
+	o.xlane = take(4 * XROWS);  // (compact: kCXrows used)
 	o.colpos = take(4 * kWave);
 	o.vlist = take(4 * kWave);
 	o.total = off + 256;  // readable tail: full-width (NR) vector reads may run past the last array
@@ -117,6 +141,11 @@ __host__ __device__ inline LdsOff lds_offsets(const SolveArgs &a)
 struct Lds {
 	ldsd *Z, *x, *G, *g, *vs, *s, *c, *TV, *S, *BL, *r0, *rho, *a0, *tau, *rdiag, *rhs, *X, *tmp, *dump, *b3;
 	ldsi *pivlane, *W, *xlane, *colpos, *vlist;
+	int ldv;    // leading dimension of the reflector store (LDV; the compact layout: per level)
+	int xrows;  // capacity of the dependent-column store X
+	// scratch of the reference replay: the chain of bases, and the projected block with its kernel matrix
+	ldsd *rpZ, *rpM;
+	int rpZcap, rpMcap;
 	unsigned long long *dbgp;  // HOQP_PROFILE builds: this instance's cycle-stamp slots (else null)
 };
 
@@ -149,6 +178,19 @@ __device__ __forceinline__ Lds lds_bind(const SolveArgs &a, HOQP_LDS char *base)
 	l.xlane = (ldsi *)(base + o.xlane);
 	l.colpos = (ldsi *)(base + o.colpos);
 	l.vlist = (ldsi *)(base + o.vlist);
+	l.ldv = LDV;
+	l.xrows = a.compact ? kCXrows : XROWS;
+	if (a.compact) {
+		l.rpZ = l.G;
+		l.rpZcap = kCReplayZ;
+		l.rpM = l.G + kCReplayZ;
+		l.rpMcap = a.Ptot * kCLd + kCTv + kCXrows * kCLd - kCReplayZ;
+	} else {
+		l.rpZ = l.G;
+		l.rpZcap = (a.Ptot ? a.Ptot : 1) * a.ld;
+		l.rpM = l.TV;
+		l.rpMcap = (LDV * a.n > a.ld * a.mmax) ? LDV * a.n : a.ld * a.mmax;
+	}
 #ifdef HOQP_PROFILE
 	l.dbgp = a.dbg ? a.dbg + (size_t)blockIdx.x * kDbgSlots : nullptr;
 #else
@@ -316,7 +358,7 @@ __device__ __forceinline__ int panel_factor_t(double (&x)[NSP][NT], int (&pos)[N
 			break;
 		PF_T(2);
 		const int pc = pq & 15, ps = pq >> 4;
-		ldsd *vr = VR + k * LDV;
+		ldsd *vr = VR + k * l.ldv;
 		if (c == pc) {
 #pragma unroll
 			for (int sl = 0; sl < NS; ++sl) {
@@ -487,7 +529,7 @@ __device__ __forceinline__ void rows_apply_reflectors_t(ldsd *A0, int n0, ldsd *
 		}
 	}
 	for (int k = ka; k < kb; ++k) {
-		const ldsd *vr = VR + k * LDV;
+		const ldsd *vr = VR + k * l.ldv;
 		double tk = l.tau[k];
 		double vv[NT];
 #pragma unroll
@@ -619,7 +661,7 @@ __device__ __forceinline__ double hh_apply_vec(double vi, int nr, int ka, int kb
 	const int lane = lane_id();
 	for (int t = 0; t < kb - ka; ++t) {
 		int k = forward ? ka + t : kb - 1 - t;
-		double v = sel(lane >= k && lane < nr, l.TV[k * LDV + (lane & (NR - 1))]);
+		double v = sel(lane >= k && lane < nr, l.TV[k * l.ldv + (lane & (NR - 1))]);
 		double s = wave_sum(v * vi) * l.tau[k];
 		vi = fma(-s, v, vi);
 	}
@@ -637,7 +679,7 @@ __device__ __forceinline__ void load_Lrow(double (&Lrow)[NR], int k1, int rb, co
 {
 	const int lane = lane_id();
 	const bool act = lane < rb;
-	const ldsd *vr = l.TV + (k1 + (act ? lane : 0)) * LDV + k1;
+	const ldsd *vr = l.TV + (k1 + (act ? lane : 0)) * l.ldv + k1;
 	// only the blocks of 8 below rb are loaded and masked (one scalar branch per block)
 #pragma unroll
 	for (int b = 0; b < NR / 8; ++b) {
@@ -663,7 +705,8 @@ __device__ __forceinline__ void load_Urow(double (&Urow)[NR], int k1, int rb, co
 {
 	const int lane = lane_id();
 	const bool act = lane < rb;
-	const ldsd *vc = l.TV + k1 * LDV + k1 + (act ? lane : 0);
+	const int ldv = l.ldv;
+	const ldsd *vc = l.TV + k1 * ldv + k1 + (act ? lane : 0);
 #pragma unroll
 	for (int b = 0; b < NR / 8; ++b) {
 		if (8 * b >= rb) {
@@ -674,7 +717,7 @@ __device__ __forceinline__ void load_Urow(double (&Urow)[NR], int k1, int rb, co
 		}
 #pragma unroll
 		for (int j = 8 * b; j < 8 * b + 8; ++j)
-			Urow[j] = vc[(j < rb ? j : 0) * LDV];
+			Urow[j] = vc[(j < rb ? j : 0) * ldv];
 #pragma unroll
 		for (int j = 8 * b; j < 8 * b + 8; ++j)
 			pin(Urow[j]);
@@ -872,7 +915,7 @@ __device__ __forceinline__ double ls_solve_reg(int k1, int k2, int qB0, int qB1,
 	for (int j = 0; j < NR; ++j)
 		Srow[j] = 0.0;
 	for (int p = 0; p < rb; ++p) {  // pivoted column at position p: e_i = R(i,p), i < p ; R(p,p)
-		const ldsd *vr = VR + (k1 + p) * LDV + k1;
+		const ldsd *vr = VR + (k1 + p) * l.ldv + k1;
 		const double dp = l.rdiag[k1 + p];
 		const double ei = (lane < p) ? vr[lane] : (lane == p ? dp : 0.0);
 #pragma unroll
@@ -951,7 +994,7 @@ __device__ __forceinline__ double ls_solve_reg(int k1, int k2, int qB0, int qB1,
 		double acc = 0.0;
 		if (act) {
 			for (int p = lane; p < rb; ++p) {
-				const double e = (p == lane) ? l.rdiag[k1 + p] : VR[(k1 + p) * LDV + k1 + lane];
+				const double e = (p == lane) ? l.rdiag[k1 + p] : VR[(k1 + p) * l.ldv + k1 + lane];
 				acc = fma(e, l.rhs[l.pivlane[k1 + p]], acc);
 			}
 			for (int u = 0; u < nunp; ++u)
@@ -968,7 +1011,7 @@ __device__ __forceinline__ double ls_solve_reg(int k1, int k2, int qB0, int qB1,
 		double acc = rc;
 		if (mypos >= k1 && mypos < k2) {
 			const int p = mypos - k1;
-			const ldsd *vr = VR + mypos * LDV + k1;
+			const ldsd *vr = VR + mypos * l.ldv + k1;
 			for (int i = 0; i < p; ++i)
 				acc = fma(-vr[i], l.tmp[i], acc);
 			acc = fma(-l.rdiag[mypos], l.tmp[p], acc);
@@ -1562,6 +1605,7 @@ struct LevelState {
 	int Pout;  // inequality rows emitted so far (offset of this level's slacks in out.v)
 	int status;
 	int replay_ok;	// every level so far can be replayed literally (see ref_replay)
+	int bail;	// compact layout: the state does not fit (HOQP_STATUS_BASE_RANK), no further level is run
 	unsigned long long t_last;
 };
 
@@ -1582,12 +1626,11 @@ __device__ __forceinline__ int unp_index(bool unp, int &base)
 // Returns p_i in lane i; *k1_out = rank of the working set (reflectors [0,k1) stay in TV).
 // ---------------------------------------------------------------------------
 template <bool HARD, bool VL = false>
-__device__ __forceinline__ double eqp_step(const SolveArgs &a, const Lds &l, LevelState &st, int nz, int rank, int m, int w_in,
-				  int nV, int *k1_out, bool *overflow)
+__device__ __forceinline__ double eqp_step(const SolveArgs &a, const Lds &l, LevelState &st, int ld, int nz, int rank, int m,
+				  int w_in, int nV, int *k1_out, bool *overflow)
 {
 	const int w = HARD ? w_in : 0;  // no stored hard rows: the working set is always empty
 	const int lane = lane_id(), s = lane & 3, c = lane >> 2;
-	const int ld = a.ld;
 	const int nb = m + nV;
 	const int ncol = w + nb;
 	*k1_out = 0;
@@ -1649,7 +1692,7 @@ __device__ __forceinline__ double eqp_step(const SolveArgs &a, const Lds &l, Lev
 			const int q = c + 16 * sl;
 			const bool unp = pos[sl] == -1 && q >= w;
 			const int u = unp_index(unp, nunp);
-			if (unp && u < XROWS) {
+			if (unp && u < l.xrows) {
 				ldsd *xr = l.X + u * ld;
 				t_upto(nz, s, [&](int t, bool on) {
 					if (on)
@@ -1660,7 +1703,7 @@ __device__ __forceinline__ double eqp_step(const SolveArgs &a, const Lds &l, Lev
 			}
 		}
 		nunp = uni(nunp);
-		if (nunp > XROWS) {
+		if (nunp > l.xrows) {
 			*overflow = true;
 			return 0.0;
 		}
@@ -2037,51 +2080,70 @@ __device__ __forceinline__ void reg_qr_steps(double (&w)[kRegC + 1], int C, int 
 	}
 }
 
-// zout (nz) = argmin |M z - r|^2 + eps |z|^2, M (m x nz, stride nz) and r in LDS, by Householder QR
-// of the stacked system, one row per lane, the row held in registers (C = min(m, nz) <= kRegC columns
-// plus the right-hand side; the column loops are unrolled over kRegC with wave-uniform guards):
-//   m > nz:  [M; sqrt(eps) I] z = [r; 0];   m <= nz (dual):  z = M' w with [M'; sqrt(eps) I] w = [0; r / sqrt(eps)].
-__device__ __forceinline__ void lds_reg_solve(const ldsd *M, const ldsd *r, int m, int nz, double eps, ldsd *wv, ldsd *zout)
+// zout (nz) = argmin |M z - r|^2 + eps |z|^2, M (m x nz, stride nz) and r in LDS, by Householder QR,
+// one row per lane, the row held in registers (C = min(m, nz) <= kRegC columns plus the right-hand side;
+// the column loops are unrolled over kRegC with wave-uniform guards):
+//   m > nz:  the stacked system [M; sqrt(eps) I] z = [r; 0].
+//   m <= nz: z lies in range(M') = range(Q) of the QR M' = Q R, so z = Q y = M' R^-1 y with
+//            y = argmin |R' y - r|^2 + eps |y|^2, again a stacked system [R'; sqrt(eps) I] y = [r; 0] (2m x m).
+//            (Round 2 solved [M'; sqrt(eps) I] w = [0; r / sqrt(eps)], z = M' w: the same minimiser on paper, but a
+//            least-squares problem whose residual is ~ |r| / sqrt(eps) = 1e6 |r|, and the error of a QR solve
+//            grows with kappa^2 x residual: 2e-5 relative at sigma_min(M) = 1e-6.  Both stacked systems here
+//            have residuals of the size of r: errors ~ u kappa.)
+// T: scratch for an m x m matrix (m <= nz case).
+__device__ __forceinline__ void lds_reg_solve(const ldsd *M, const ldsd *r, int m, int nz, double eps, ldsd *wv, ldsd *zout,
+					      ldsd *T)
 {
 	const int lane = lane_id();
 	const bool dual = m <= nz;
-	const int C = dual ? m : nz, R = m + nz;
+	const int C = dual ? m : nz;
 	const double se = sqrt(eps);
 	double w[kRegC + 1];
-	// the lane's row: all loads first (clamped addresses), then the selects
-	{
+	if (dual) {
+		// ---- R of M' = Q R: lane q < nz holds row q of M' ----
+		{
+			double ld_[kRegC];
+#pragma unroll
+			for (int j = 0; j < kRegC; ++j)
+				ld_[j] = M[((j < C) ? j : 0) * nz + (lane < nz ? lane : 0)];
+#pragma unroll
+			for (int j = 0; j < kRegC; ++j)
+				w[j] = (j < C && lane < nz) ? ld_[j] : 0.0;
+			w[kRegC] = 0.0;
+		}
+		reg_qr_steps<0>(w, C, nz);
+		// T[i][j] = R(i, j): lane i < m holds row i of R in w[i..m)
+#pragma unroll
+		for (int j = 0; j < kRegC; ++j)
+			if (j < C && lane < m)
+				T[lane * m + j] = (j >= lane) ? w[j] : 0.0;
+		wave_sync();
+		// ---- stacked system [R'; sqrt(eps) I] y = [r; 0]: lane i < m holds row i of R' ----
+		{
+			double ld_[kRegC + 1];
+#pragma unroll
+			for (int j = 0; j < kRegC; ++j)
+				ld_[j] = T[((j < C) ? j : 0) * m + (lane < m ? lane : 0)];
+			ld_[kRegC] = r[lane < m ? lane : 0];
+#pragma unroll
+			for (int j = 0; j < kRegC; ++j)
+				w[j] = (j < C) ? ((lane < m) ? ld_[j] : ((lane - m == j) ? se : 0.0)) : 0.0;
+			w[kRegC] = (lane < m) ? ld_[kRegC] : 0.0;
+		}
+		reg_qr_steps<0>(w, C, 2 * m);
+	} else {
+		// the lane's row: all loads first (clamped addresses), then the selects
 		double ld_[kRegC + 1];
 #pragma unroll
-		for (int j = 0; j <= kRegC; ++j) {
-			const int jc = (j < C) ? j : 0;
-			const ldsd *src;
-			if (dual)
-				src = (j < C) ? M + jc * nz + (lane < nz ? lane : 0) : r + ((lane >= nz && lane < R) ? lane - nz : 0);
-			else
-				src = (j < C) ? M + (lane < m ? lane : 0) * nz + jc : r + (lane < m ? lane : 0);
-			ld_[j] = *src;
-		}
+		for (int j = 0; j <= kRegC; ++j)
+			ld_[j] = (j < C) ? M[(lane < m ? lane : 0) * nz + ((j < C) ? j : 0)] : r[lane < m ? lane : 0];
 #pragma unroll
-		for (int j = 0; j <= kRegC; ++j) {
-			double v = 0.0;
-			const int jj = (j == kRegC) ? C : j;  // slot kRegC holds the right-hand side
-			(void)jj;
-			if (dual) {
-				if (j < kRegC)
-					v = (j < C) ? ((lane < nz) ? ld_[j] : ((lane - nz == j && lane < R) ? se : 0.0)) : 0.0;
-				else
-					v = (lane >= nz && lane < R) ? ld_[kRegC] / se : 0.0;
-			} else {
-				if (j < kRegC)
-					v = (j < C) ? ((lane < m) ? ld_[j] : ((lane - m == j && lane < R) ? se : 0.0)) : 0.0;
-				else
-					v = (lane < m) ? ld_[kRegC] : 0.0;
-			}
-			w[j] = v;
-		}
+		for (int j = 0; j < kRegC; ++j)
+			w[j] = (j < C) ? ((lane < m) ? ld_[j] : ((lane - m == j && lane < m + nz) ? se : 0.0)) : 0.0;
+		w[kRegC] = (lane < m) ? ld_[kRegC] : 0.0;
+		reg_qr_steps<0>(w, C, m + nz);
 	}
-	reg_qr_steps<0>(w, C, R);
-	// back substitution: lane i holds row i of R and the transformed right-hand side
+	// back substitution: lane i holds row i of the triangular factor and the transformed right-hand side
 	double acc = w[kRegC];
 #pragma unroll
 	for (int i = kRegC - 1; i >= 0; --i) {
@@ -2093,6 +2155,18 @@ __device__ __forceinline__ void lds_reg_solve(const ldsd *M, const ldsd *r, int 
 			wv[i] = si;
 	}
 	wave_sync();
+	if (dual) {
+		// w = R^-1 y (R in T, one row per lane), then z = M' w
+		double acc2 = wv[lane < m ? lane : 0];
+		for (int i = m - 1; i >= 0; --i) {
+			const double si = readlane_d(acc2 / T[(lane < m ? lane : 0) * m + (lane < m ? lane : 0)], i);
+			acc2 = fma(-T[(lane < m ? lane : 0) * m + i], si, acc2);
+			wave_sync();
+			if (lane == 0)
+				wv[i] = si;
+		}
+		wave_sync();
+	}
 	if (lane < nz) {
 		double z = 0.0;
 		if (dual) {
@@ -2112,8 +2186,9 @@ __device__ __forceinline__ bool ref_replay(const SolveArgs &a, const Lds &l, int
 					   const WbcCtx &wx, const int (&jc)[NR / 4], double *res2_out)
 {
 	const int lane = lane_id();
-	const int Gcap = (a.Ptot ? a.Ptot : 1) * a.ld;
-	const int tvcap = (LDV * a.n > a.ld * a.mmax) ? LDV * a.n : a.ld * a.mmax;
+	// scratch: ZB holds the chain of bases, MK the projected block M and its kernel matrix K (lds_bind)
+	ldsd *ZB = l.rpZ, *MK = l.rpM;
+	const int Gcap = l.rpZcap, tvcap = l.rpMcap;
 	ldsd *xr = l.tmp, *zv = l.tmp + NR, *wv = l.tau;
 #ifdef HOQP_REPLAY_DEBUG
 #define RDBG(...) do { if (lane == 0) printf(__VA_ARGS__); } while (0)
@@ -2147,7 +2222,7 @@ __device__ __forceinline__ bool ref_replay(const SolveArgs &a, const Lds &l, int
 	if (lane < NR)
 		xr[lane] = (lane < n) ? l.x[lane] - l.S[lane] : 0.0;
 	wave_sync();
-	const ldsd *Zr = l.G;
+	const ldsd *Zr = ZB;
 	bool zident = true;  // Zr is the identity so far (no null tests on LDS pointers: offset 0 is a valid address)
 	int nzr = n, zoff = 0;
 	for (int j = 0; j <= k; ++j) {
@@ -2167,14 +2242,15 @@ __device__ __forceinline__ bool ref_replay(const SolveArgs &a, const Lds &l, int
 			return false;  // the LU's rank decisions differ from the QR's: leave the fast answer
 		const int cmin = min(mj, nzr);
 		RDBG("[replay]  level %d m %d nzr %d\n", j, mj, nzr);
-		// TV: M (mj x nzr) and, for j < k, the kernel matrix (nzr x (nzr - rank), rank = mj unless deficient)
-		if (mj * nzr + (j < k ? nzr * (nzr - cmin) : 0) > tvcap || cmin > kRegC || mj + nzr > kWave)
+		// MK: M (mj x nzr) and, for j < k, the kernel matrix (nzr x (nzr - rank), rank = mj unless deficient;
+		// from the identity the kernel matrix IS the new basis and is built in ZB directly)
+		if (mj * nzr + (j < k ? (zident ? 0 : nzr * (nzr - cmin)) : cmin * cmin) > tvcap || cmin > kRegC || mj + nzr > kWave)
 			return false;
 		{
 			// M = A_j Zr -> TV (stride nzr),  r = b_j - A_j xr -> l.rhs
 			double bm[NR / 4][2];
 			load_bm_from(bm, n, nzr, nzr, Zr, xr, zident);
-			const ProjDst dst = {l.TV, nzr, l.rhs};
+			const ProjDst dst = {MK, nzr, l.rhs};
 			if (WBC) {
 				if (j == 0) {
 					WbcEntrySrc<0> src(wx, a.wprm, l, jc);
@@ -2196,14 +2272,14 @@ __device__ __forceinline__ bool ref_replay(const SolveArgs &a, const Lds &l, int
 		}
 		RSTAMP(33);
 		if (j == k) {
-		lds_reg_solve(l.TV, l.rhs, mj, nzr, a.eps, wv, zv);
+		lds_reg_solve(MK, l.rhs, mj, nzr, a.eps, wv, zv, MK + mj * nzr);
 		RSTAMP(34);
 		{  // |A_k x_k - b_k|^2 at the regularised optimum
 			double ri = 0.0;
 			if (lane < mj) {
 				ri = l.rhs[lane];
 				for (int q = 0; q < nzr; ++q)
-					ri = fma(-l.TV[lane * nzr + q], zv[q], ri);
+					ri = fma(-MK[lane * nzr + q], zv[q], ri);
 			}
 			*res2_out = wave_sum(ri * ri);
 		}
@@ -2231,7 +2307,7 @@ __device__ __forceinline__ bool ref_replay(const SolveArgs &a, const Lds &l, int
 		RSTAMP(35);
 		}
 		if (j < k) {
-			const int rank = uni(lds_fullpivlu(l.TV, mj, nzr, l.colpos));
+			const int rank = uni(lds_fullpivlu(MK, mj, nzr, l.colpos));
 			RSTAMP(36);
 			const int dk = nzr - rank;
 			RDBG("[replay]  level %d rank %d\n", j, rank);
@@ -2239,25 +2315,23 @@ __device__ __forceinline__ bool ref_replay(const SolveArgs &a, const Lds &l, int
 				nzr = 0;
 				continue;
 			}
-			if (mj * nzr + nzr * dk > tvcap)
-				return false;
-			ldsd *K = l.TV + mj * nzr;
-			lds_lu_kernel(l.TV, nzr, rank, l.colpos, K);
-			RSTAMP(37);
 			const int newoff = (zident || zoff != 0) ? 0 : n * nzr;
 			if (newoff + n * dk > Gcap || (!zident && newoff == 0 && n * dk > zoff))
 				return false;
-			ldsd *Zn = l.G + newoff;
+			ldsd *Zn = ZB + newoff;
+			if (!zident && mj * nzr + nzr * dk > tvcap)
+				return false;
+			ldsd *K = zident ? Zn : MK + mj * nzr;  // from the identity: Zn = I K (nzr == n)
+			lds_lu_kernel(MK, nzr, rank, l.colpos, K);
+			RSTAMP(37);
 			// Zn (n x dk) = Zr K: one output entry per lane and pass, the dot product in blocks of
 			// eight terms whose loads are in flight together (same summation order as a plain loop)
-			for (int e0 = 0; e0 < n * dk; e0 += kWave) {
+			for (int e0 = 0; e0 < (zident ? 0 : n * dk); e0 += kWave) {
 				const int e = e0 + lane;
 				const bool on = e < n * dk;
 				const int row = on ? e / dk : 0, q = on ? e - (e / dk) * dk : 0;
 				double sacc = 0.0;
-				if (zident) {
-					sacc = K[row * dk + q];
-				} else {
+				{
 					for (int t0 = 0; t0 < nzr; t0 += 8) {
 						double za[8], kb[8];
 #pragma unroll
@@ -2306,13 +2380,22 @@ __device__ __forceinline__ bool ref_replay(const SolveArgs &a, const Lds &l, int
 // level loop has no far backward jump (measured: ~2 k cycles of instruction fetch per back-edge of the
 // 380 KB loop body).
 template <bool GATE, bool HARD, bool WBC, int KC = -1>
-__device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, LevelState &st, int inst, int k_rt, int m, int p,
+__device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l_in, LevelState &st, int inst, int k_rt, int m, int p,
 					    const WbcCtx &wx, const int (&jc)[NR / 4])
 {
 	const int k = (KC >= 0) ? KC : k_rt;
 	HOQP_STAMP(45);
 	const int lane = lane_id(), s = lane & 3, c = lane >> 2;
-	const int n = uni(st.n), ld = a.ld;
+	// the specialised level copies of the fused reference kernel run on the compact LDS layout (hoqp_solve.hpp
+	// head): compile-time leading dimensions; ldt: the projected rows of this level in TV
+	constexpr bool COMPACT = WBC && GATE && !HARD && KC >= 0;
+	const int n = uni(st.n), ld = COMPACT ? kCLd : a.ld;
+	const int ldt = (COMPACT && KC == 0) ? kCLd0 : ld;
+	Lds l = l_in;
+	if (COMPACT) {
+		l.ldv = (KC == 0) ? LDV : kCLdv;
+		l.xrows = kCXrows;
+	}
 	const int nz = uni(st.nz), P = HARD ? uni(st.P) : 0;
 	const int nstore = a.n;
 	if (WBC && KC >= 0) {
@@ -2354,7 +2437,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 	// ---- 1. project the task into the current null space (ConstructH/C/D/FVector,
 	//         ho_qp_problem.cpp:180-285, in factored form) ----
 	auto project = [&](bool doA, bool doD) {
-		const ProjDst dstT = {l.TV, ld, l.rhs}, dstG = {l.G + P * ld, ld, l.g + P};
+		const ProjDst dstT = {l.TV, ldt, l.rhs}, dstG = {l.G + P * ld, ld, l.g + P};
 		if (WBC && k == 4) {
 			// ConstructForceMinimizationTask: A = [0 I], b = 0, so A Z is rows 18.. of Z and A x the
 			// contact forces -- copied, not multiplied (the products are exact either way)
@@ -2364,7 +2447,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 #endif
 				for (int idx = lane; idx < m * nz; idx += kWave) {
 					const int r = idx / nz, j = idx - r * nz;
-					l.TV[r * ld + j] = l.Z[(kNU + r) * ld + j];
+					l.TV[r * ldt + j] = l.Z[(kNU + r) * ld + j];
 				}
 				if (lane < m)
 					l.rhs[lane] = 0.0 - l.x[kNU + lane];
@@ -2376,7 +2459,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 			}
 		} else if (WBC && k == 0) {
 			if (m > 0 && doA)
-				wbc_project_level0(wx, ld, l);
+				wbc_project_level0(wx, ldt, l);
 		} else if (WBC) {  // fused entry (n <= 30: always the matrix-core path)
 			double bm[NR / 4][2];
 #ifdef HOQP_PROFILE
@@ -2460,8 +2543,8 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 #pragma unroll
 			for (int u = 0; u < 4; ++u) {
 				const int r = (r0 + u < m) ? r0 + u : 0;
-				ai[u] = l.TV[r * ld + ci];
-				aj[u] = l.TV[r * ld + cj];
+				ai[u] = l.TV[r * ldt + ci];
+				aj[u] = l.TV[r * ldt + cj];
 				rr[u] = l.rhs[r];
 			}
 #pragma unroll
@@ -2486,7 +2569,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 			double tv[8];
 #pragma unroll
 			for (int i = 0; i < 8; ++i)
-				tv[i] = l.TV[rc * ld + (i < nz ? i : 0)];
+				tv[i] = l.TV[rc * ldt + (i < nz ? i : 0)];
 			double res = l.rhs[rc];
 #pragma unroll
 			for (int i = 0; i < 8; ++i)
@@ -2513,7 +2596,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 				const int q = c + 16 * sl;
 				const bool has = q <= nz;
 				const ldsd *src = (q < nz) ? l.TV + q : l.rhs;
-				const int stride = (q < nz) ? ld : 1;
+				const int stride = (q < nz) ? ldt : 1;
 #pragma unroll
 				for (int t = 0; t < NT; ++t)
 					x[sl][t] = src[(s + 4 * t) * stride];
@@ -2565,7 +2648,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 					double e[NT];
 #pragma unroll
 					for (int t = 0; t < NT; ++t)
-						e[t] = l.TV[(pj[t] > 0 ? pj[t] : 0) * LDV + (hasr ? pr : 0)];
+						e[t] = l.TV[(pj[t] > 0 ? pj[t] : 0) * l.ldv + (hasr ? pr : 0)];
 #pragma unroll
 					for (int t = 0; t < NT; ++t)
 						pin(e[t]);
@@ -2624,7 +2707,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 				continue;
 			const int q = c + 16 * sl;
 			const bool has = q < m;
-			const ldsd *src = l.TV + (has ? q : 0) * ld;
+			const ldsd *src = l.TV + (has ? q : 0) * ldt;
 			ld8(x[sl], src + s);
 			pos[sl] = has ? -1 : -2;
 		}
@@ -2638,6 +2721,13 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 		wave_sync();  // every column is in registers before TV is reused as the reflector store
 		rank = uni(panel_factor<(WBC && GATE && !HARD && KC >= 0)>(x, pos, nslot, 0, m, nz, 0, kEpsMach * (double)max(m, nz), l, HOQP_DBGP));
 		HOQP_STAMP(2);
+		if (COMPACT && KC == 0 && rank != kNB) {
+			// [M_fb, -J_c,fb^T] without full row rank (not a physical mass matrix): more than 24 free
+			// coordinates would be left, which the compact layout has no room for
+			st.status |= HOQP_STATUS_BASE_RANK;
+			st.bail = 1;
+			return;
+		}
 		int nunp = 0;
 		int uidx[NSP];
 #pragma unroll
@@ -2675,7 +2765,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 		}
 		if ((!consider || tryfast) && rank > 0) {
 			// ---- 4a. unconstrained level: y1 = argmin |R' y1 - r| (+ eps term), y2 = 0 ----
-			if (nunp > XROWS) {
+			if (nunp > l.xrows) {
 				if (!consider)
 					st.status |= HOQP_STATUS_WORKSPACE;
 			} else {
@@ -2857,7 +2947,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 						a.dbg[(size_t)blockIdx.x * kDbgSlots + 50] += 1;  // steps through the small side
 #endif
 				} else
-				pi = eqp_step<HARD, (WBC && GATE && !HARD && KC >= 0)>(a, l, st, nz, rank, mB, w, nV, &k1, &overflow);
+				pi = eqp_step<HARD, (WBC && GATE && !HARD && KC >= 0)>(a, l, st, ld, nz, rank, mB, w, nV, &k1, &overflow);
 				if (overflow) {
 					st.status |= HOQP_STATUS_WORKSPACE;
 					break;
@@ -2894,7 +2984,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l, Le
 					if (lane == i)
 						mu = mi;
 					if (lane < i)
-						acc = fma(-l.TV[i * LDV + lane], mi, acc);
+						acc = fma(-l.TV[i * l.ldv + lane], mi, acc);
 				}
 				int wi = (lane < k1) ? l.pivlane[lane] : -1;  // pivot column == position in W
 				int drop;
@@ -3292,10 +3382,7 @@ __device__ __forceinline__ void wbc_tail(const SolveArgs &a, const Lds &l, const
 #endif  // __HIP_DEVICE_COMPILE__
 
 template <bool GATE, bool HARD, bool WBC>
-#ifdef HOQP_WAVES_PER_EU
-__attribute__((amdgpu_waves_per_eu(HOQP_WAVES_PER_EU, HOQP_WAVES_PER_EU)))
-#endif
-__global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
+__device__ __forceinline__ void hoqp_solve_body(const SolveArgs &a)
 {
 #ifdef __HIP_DEVICE_COMPILE__
 	extern __shared__ __align__(16) char smem[];
@@ -3307,6 +3394,7 @@ __global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
 	LevelState st;
 	st.status = 0;
 	st.replay_ok = 1;
+	st.bail = 0;
 	WbcCtx wx = {};
 	int jc[NR / 4] = {-1, -1, -1, -1, -1, -1, -1, -1};
 	if (WBC) {
@@ -3411,10 +3499,33 @@ __global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
 	if (WBC && GATE && !HARD) {
 		// the reference's WBC hierarchy (fill_args: L == 5): five specialised copies
 		run_level(std::integral_constant<int, 0>{}, 0);
-		run_level(std::integral_constant<int, 1>{}, 1);
-		run_level(std::integral_constant<int, 2>{}, 2);
-		run_level(std::integral_constant<int, 3>{}, 3);
-		run_level(std::integral_constant<int, 4>{}, 4);
+		if (!st.bail) {
+			run_level(std::integral_constant<int, 1>{}, 1);
+			run_level(std::integral_constant<int, 2>{}, 2);
+			run_level(std::integral_constant<int, 3>{}, 3);
+			run_level(std::integral_constant<int, 4>{}, 4);
+		} else {
+			// HOQP_STATUS_BASE_RANK: nothing was solved; every output says so
+			wave_sync();
+			if (lane < NR)
+				l.x[lane] = __builtin_nan("");
+			if (lane < a.L) {
+				const size_t o = (size_t)inst * a.L + lane;
+				if (a.out.level_res)
+					a.out.level_res[o] = __builtin_nan("");
+				if (a.out.iters)
+					a.out.iters[o] = 0;
+				if (a.out.nz_levels)
+					a.out.nz_levels[o] = 0;
+			}
+			if (a.out.x_levels)
+				for (int i = lane; i < a.L * a.n; i += kWave)
+					a.out.x_levels[(size_t)inst * a.L * a.n + i] = __builtin_nan("");
+			if (a.out.v)
+				for (int i = lane; i < a.Ptot; i += kWave)
+					a.out.v[(size_t)inst * a.Ptot + i] = __builtin_nan("");
+			wave_sync();
+		}
 	} else {
 		for (int k = 0; k < a.L; ++k)
 			run_level(std::integral_constant<int, -1>{}, k);
@@ -3515,6 +3626,28 @@ __global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
 		a.out.status[inst] = st.status;
 	HOQP_STAMP(7);
 #endif  // __HIP_DEVICE_COMPILE__
+}
+
+// Generic instantiations (stored task blocks; the fused WBC entry under paper semantics): one wave per SIMD.
+template <bool GATE, bool HARD, bool WBC>
+#ifdef HOQP_WAVES_PER_EU
+__attribute__((amdgpu_waves_per_eu(HOQP_WAVES_PER_EU, HOQP_WAVES_PER_EU)))
+#endif
+__global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
+{
+	hoqp_solve_body<GATE, HARD, WBC>(a);
+}
+
+// The fused WBC entry under reference semantics (the benchmarked kernel): compact LDS layout (six workgroups
+// per CU) and the register budget of two waves per SIMD (256 registers per lane in total; the compiler would
+// otherwise take 256 + 45 accumulation registers, which pins the kernel at one wave per SIMD whatever the LDS).
+#ifndef HOQP_WBC_REF_WAVES
+#define HOQP_WBC_REF_WAVES 2
+#endif
+__attribute__((amdgpu_waves_per_eu(HOQP_WBC_REF_WAVES, HOQP_WBC_REF_WAVES)))
+__global__ void __launch_bounds__(kWave) hoqp_solve_wbc_ref_kernel(const SolveArgs a)
+{
+	hoqp_solve_body<true, false, true>(a);
 }
 
 }  // namespace hoqp

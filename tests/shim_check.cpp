@@ -42,6 +42,15 @@ static void print_vec(const char *name, const VectorXd &v)
 	std::printf("\n");
 }
 
+static void print_mat(const char *name, const MatrixXd &m)
+{
+	std::printf("%s %d %d", name, (int)m.rows(), (int)m.cols());
+	for (int i = 0; i < m.rows(); ++i)
+		for (int j = 0; j < m.cols(); ++j)
+			std::printf(" %.17g", m(i, j));
+	std::printf("\n");
+}
+
 int main(int argc, char **argv)
 {
 	if (argc < 2)
@@ -85,7 +94,14 @@ int main(int argc, char **argv)
 			print_vec("x", opt_problems[i]->GetSolution());
 			print_vec("v", opt_problems[i]->GetStackedSlackSolutions());
 		}
+		// GetStackedTasks by VALUE: StackTasks puts the current task first (ho_qp_problem.cpp:83-86 with
+		// ConcatenateTasks(curr, prev), task_definition.hpp:13-30)
 		TaskDefinition st = opt_problems.back()->GetStackedTasks();
+		print_mat("stackedA", st.A);
+		print_vec("stackedb", st.b);
+		print_mat("stackedD", st.D);
+		print_vec("stackedf", st.f);
+		print_vec("vlast", opt_problems.back()->GetSlackSolutions());
 		std::printf("stacked %d %d\n", (int)st.A.rows(), (int)st.D.rows());
 	} else {
 		std::vector<double> M(324), h(18), Jf(216), Jdu(12), fp(12), Jb(108);

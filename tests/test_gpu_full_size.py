@@ -191,7 +191,7 @@ def test_near_singular_family(solver_factory, oracle):
     u = 2.0 ** -53
     smax = 0.7
     floor = 4.0 * u * smax / np.sqrt(smin ** 2 + EPS) * np.abs(ref["x"]).max(axis=1)
-    assert (floor < 1e-7).sum() >= 300
+    assert (floor < 1e-7).sum() >= 250
     xerr = np.abs(o["x"] - ref["x"])
     assert np.all(xerr.max(axis=1) <= RTOL * np.maximum(1.0, np.abs(ref["x"]).max(axis=1))), "x, norm-wise"
     for key, width in (("x", 30), ("qdd", 12), ("tau", 12), ("v", 40), ("level_res", 5)):

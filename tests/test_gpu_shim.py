@@ -59,6 +59,22 @@ def test_shim_problem_chain(tmp_path, oracle, mode, sem):
     # last level: 9 equality rows in 9 variables -> unique x
     assert np.allclose(xs[-1], ref["x_levels"][-1], rtol=1e-6, atol=1e-6)
     assert out[-1].split() == ["stacked", str(sum(m for m, _ in spec)), str(sum(p for _, p in spec))]
+    # contents and ORDER of the stacked task of the last problem: the current task first, then the previous
+    # stack (ho_qp_problem.cpp:83-86, task_definition.hpp:13-30), i.e. newest level first; bit-exact copies
+    def mat(name):
+        f = [l for l in out if l.startswith(name + " ")][0].split()
+        return np.array(f[3:], dtype=float).reshape(int(f[1]), int(f[2]))
+
+    def vec(name):
+        f = [l for l in out if l.startswith(name + " ")][0].split()
+        return np.array(f[2:], dtype=float)
+
+    newest_first = list(reversed(tasks))
+    assert np.array_equal(mat("stackedA"), np.concatenate([t["A"] for t in newest_first if "A" in t]))
+    assert np.array_equal(vec("stackedb"), np.concatenate([t["b"] for t in newest_first if "b" in t]))
+    assert np.array_equal(mat("stackedD"), np.concatenate([t["D"] for t in newest_first if "D" in t]))
+    assert np.array_equal(vec("stackedf"), np.concatenate([t["f"] for t in newest_first if "f" in t]))
+    assert vec("vlast").size == spec[-1][1]      # GetSlackSolutions: the last level's own slacks (none here)
 
 
 def test_shim_controller(tmp_path, oracle):
