@@ -38,10 +38,10 @@ WORKLOAD_LABEL = {"stance": "configs[1]", "trot": "configs[2] (trot mix)", "thre
                   "crawl": "crawl gait of the reference via the command sampler"}
 
 
-def alg_bytes_per_solve(nc, ns):
+def alg_bytes_per_solve(nc, ns, general_jb=False):
     """SURVEY.md 8(d), fused WBC entry: inputs 8*(324 M + 18 h + 57 per leg + 6 base rhs) + 4 B mask,
-    outputs 8*(54 + 7 n_c) + 8.  5,276 B for n_c = 4."""
-    return 8 * (324 + 18 + 57 * (nc + ns) + 6) + 4 + 8 * (54 + 7 * nc) + 8
+    outputs 8*(54 + 7 n_c) + 8.  5,276 B for n_c = 4; a general J_b (6 x 18) adds 864 B."""
+    return 8 * (324 + 18 + 57 * (nc + ns) + 6) + 4 + 8 * (54 + 7 * nc) + 8 + (864 if general_jb else 0)
 
 
 def alg_flops_per_solve(nc, ns, gate):
@@ -165,16 +165,34 @@ def feasibility_match(out, inp, mode, sample, threads, prm_kw):
 
 def load_traffic(batch, mode, contact):
     """HBM bytes per launch of the dominant kernel from the committed PMC pass of this same command
-    (tools/profile.sh; separate --pmc runs).  Only for the profiled workload."""
-    for name in ("r02_pmc_traffic.json",):
+    (tools/profile.sh; separate --pmc runs, corrected by the factors tools/calib/fetch_calib.sh measured).
+    Only for the profiled workload AND the profiled binary: the file carries the SHA-256 of the library it
+    was measured on; any other library gets None and the reason."""
+    import hashlib
+
+    from quadruped_locomotion_amd import hoqp
+
+    try:
+        with open(hoqp.LIB_PATH, "rb") as f:
+            sha = hashlib.sha256(f.read()).hexdigest()
+    except OSError:
+        return None, "library not readable"
+    for name in ("r03_pmc_traffic.json",):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 tj = json.load(f)
-            if tj.get("batch") == batch and tj.get("semantics") == mode and tj.get("contact") == contact:
-                return float(tj["fetch_bytes_per_launch"] + tj["write_bytes_per_launch"]), tj.get("source")
-        except (OSError, ValueError, KeyError):
-            pass
-    return None, None
+        except (OSError, ValueError):
+            continue
+        if not (tj.get("batch") == batch and tj.get("semantics") == mode and tj.get("contact") == contact):
+            return None, f"profiles/{name} was measured on another workload"
+        if tj.get("library_sha256") != sha:
+            return None, (f"profiles/{name} was measured on another build of libhoqp_hip.so "
+                          f"(sha256 {str(tj.get('library_sha256'))[:12]}..., loaded {sha[:12]}...)")
+        try:
+            return float(tj["fetch_bytes_per_launch"] + tj["write_bytes_per_launch"]), tj.get("source")
+        except KeyError:
+            return None, f"profiles/{name} is incomplete"
+    return None, "no PMC traffic file committed"
 
 
 def main():
@@ -290,27 +308,70 @@ def main():
         dinp["leg_cmd"], dinp["contact"] = lc, ct
         solver.synchronize()
         inp["leg_cmd"], inp["contact"] = lc.cpu().numpy(), ct.cpu().numpy()
-    out = solver.alloc_wbc_outputs(nloc)
     # the per-level intermediate solutions are a diagnostic output (the reference's CalcJointCmd reads the last
     # problem's solution only, ho_qp_controller.cpp:13-16): not requested on the benchmarked path
-    out["x_levels"] = None
-    if args.skip_unread_slack:
-        out["v"] = None
+    def alloc_out():
+        o = solver.alloc_wbc_outputs(nloc)
+        o["x_levels"] = None
+        if args.skip_unread_slack:
+            o["v"] = None
+        return o
 
-    def collect():
-        # collection of results: per-instance x, tau, v*, status to rank 0 (RCCL
-        # gather), residual statistics all-reduced
-        payload = dict(x=out["x"], tau=out["tau"], status=out["status"])
-        if out["v"] is not None:
-            payload["v"] = out["v"]
-        parallel.gather_solutions(payload, total, dst=0)
-        mx, sm = parallel.local_stats(out)
+    # collection of results: per-instance x, tau, v*, status to rank 0 -- received straight
+    # into preallocated [total, ...] arrays (parallel.ResultCollector: grouped isend / irecv, RCCL) -- and the
+    # residual statistics all-reduced.  Inside the step (c4) it runs on a side stream with two output sets, so
+    # that the collection of step k overlaps the solve of step k + 1.
+    nbuf = 2 if gather_in_step else 1
+    outs = [alloc_out() for _ in range(nbuf)]
+    out = outs[0]
+    payload_keys = [k for k in ("x", "tau", "v", "status") if out.get(k) is not None]
+    collector = None
+    if world > 1 and not args.no_gather:
+        collector = parallel.ResultCollector({k: (tuple(out[k].shape[1:]), out[k].dtype) for k in payload_keys}, total,
+                                             solver.device, dst=0, buffers=nbuf)
+    side = torch.cuda.Stream() if gather_in_step else None
+    solved_ev = [torch.cuda.Event() for _ in range(nbuf)]
+    done_ev = [None] * nbuf
+    timing_on = [False]
+    solve_evs, gather_evs, gather_host = [], [], []
+
+    def collect(o, b):
+        reqs = collector.start({k: o[k] for k in payload_keys}, b)
+        collector.wait(reqs)
+        mx, sm = parallel.local_stats(o)
         return parallel.reduce_stats(mx, sm)
 
+    step_no = [0]
+
     def step():
-        solver.solve_wbc(dinp, out)
-        if gather_in_step:
-            collect()
+        b = step_no[0] % nbuf
+        step_no[0] += 1
+        main = torch.cuda.current_stream()
+        if gather_in_step and done_ev[b] is not None:
+            main.wait_event(done_ev[b])       # the collection that read this output set has finished
+        if timing_on[0] and gather_in_step:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(main)
+        solver.solve_wbc(dinp, outs[b])
+        if not gather_in_step:
+            return
+        if timing_on[0]:
+            e1.record(main)
+            solve_evs.append((e0, e1))
+        solved_ev[b].record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(solved_ev[b])
+            if timing_on[0]:
+                g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                g0.record(side)
+                h0 = time.perf_counter()
+            collect(outs[b], b)
+            if timing_on[0]:
+                g1.record(side)
+                gather_evs.append((g0, g1))
+                gather_host.append(time.perf_counter() - h0)
+            done_ev[b] = torch.cuda.Event()
+            done_ev[b].record(side)
 
     def barrier():
         if world > 1:
@@ -321,14 +382,24 @@ def main():
         step()
     barrier()
     solver.timing(True)
+    timing_on[0] = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     t1 = time.perf_counter()
+    timing_on[0] = False
     elapsed = t1 - t0
     kern_ms, kern_n = solver.kernel_time_ms()
     solver.timing(False)
+    out = outs[(step_no[0] - 1) % nbuf] if step_no[0] else outs[0]
+    step_solve_ms = step_gather_ms = None
+    if gather_in_step and solve_evs:
+        step_solve_ms = float(np.mean([a.elapsed_time(b) for a, b in solve_evs]))
+        # device time of the collection on its own stream (RCCL); on a gloo rehearsal the transfers are host
+        # calls, so the host time of the block is what there is to report
+        step_gather_ms = (float(np.mean(gather_host)) * 1e3 if dist.get_backend() == "gloo"
+                          else float(np.mean([a.elapsed_time(b) for a, b in gather_evs])))
 
     # p50/p99 batch latency (submit -> results visible), outside the timed region; SURVEY 8d: >= 1000
     # batches regardless of --steps (fewer only for batches that take longer than 10 ms each)
@@ -351,11 +422,7 @@ def main():
         ns = args.pipeline_streams
         streams = [torch.cuda.Stream() for _ in range(ns)]
         solvers = [hoqp.HoQpSolver(solver.cfg) for _ in range(ns)]
-        outs = [solver.alloc_wbc_outputs(nloc) for _ in range(ns)]
-        for o in outs:
-            o["x_levels"] = None
-            if args.skip_unread_slack:
-                o["v"] = None
+        pouts = [alloc_out() for _ in range(ns)]
         torch.cuda.synchronize()
         reps = max(args.steps, 20)
         for timed in (False, True):
@@ -363,10 +430,10 @@ def main():
             p0 = time.perf_counter()
             for i in range(reps):
                 with torch.cuda.stream(streams[i % ns]):
-                    solvers[i % ns].solve_wbc(dinp, outs[i % ns])
+                    solvers[i % ns].solve_wbc(dinp, pouts[i % ns])
             torch.cuda.synchronize()
             p1 = time.perf_counter()
-        same = all(bool(torch.equal(outs[j]["x"], out["x"])) for j in range(ns))
+        same = all(bool(torch.equal(pouts[j]["x"], out["x"])) for j in range(ns))
         pipelined = {"streams": ns, "steps": reps, "value": nloc * reps / (p1 - p0), "unit": "solves/s",
                      "ms_per_step": (p1 - p0) / reps * 1e3, "x_identical_to_single_stream": same,
                      "note": "batches of the same size issued alternately on %d streams; not the headline" % ns}
@@ -374,11 +441,11 @@ def main():
             sv.close()
 
     gather_ms, stats = None, None
-    if world > 1 and not args.no_gather:
-        collect()  # warm-up of the communicator
+    if collector is not None:
+        collect(out, 0)  # warm-up of the communicator
         barrier()
         g0 = time.perf_counter()
-        mx, sm = collect()
+        mx, sm = collect(out, 0)
         barrier()
         gather_ms = (time.perf_counter() - g0) * 1e3
         stats = dict(eq_res_max=float(mx[0]), ineq_viol_max=float(mx[1]), status_nonzero=int(sm[0]),
@@ -398,14 +465,15 @@ def main():
         nc_i, ns_i = (ct == 1).sum(axis=1), (ct == 0).sum(axis=1)
         gate = args.mode == "reference"
         pats = {(int(a), int(b)) for a, b in zip(nc_i, ns_i)}
-        bytes_mean = float(np.mean([alg_bytes_per_solve(a, b) for a, b in zip(nc_i, ns_i)]))
+        bytes_mean = float(np.mean([alg_bytes_per_solve(a, b, dinp.get("Jb") is not None) for a, b in zip(nc_i, ns_i)]))
         fl = {pt: alg_flops_per_solve(pt[0], pt[1], gate) for pt in pats}
         flops_mean = float(np.mean([fl[(int(a), int(b))] for a, b in zip(nc_i, ns_i)]))
         ach_tf = flops_mean * nloc / kern_s / 1e12 if kern_s > 0 else 0.0
         ach_gbs = bytes_mean * nloc / kern_s / 1e9 if kern_s > 0 else 0.0
         traffic, traffic_src = load_traffic(nloc, args.mode, args.contact)
         res = {
-            "metric": "fp64 HO-QP solves/sec (ANYmal-C, 4 contacts)",
+            "metric": "fp64 HO-QP solves/sec (ANYmal-C, 4 contacts)" if args.contact == "stance" else
+                      f"fp64 HO-QP solves/sec (ANYmal-C, {args.contact} contact patterns; NOT the 4-contact headline)",
             "value": value,
             "unit": "solves/s",
             "n_gpus": world,
@@ -429,13 +497,19 @@ def main():
                        "params": prm_kw or "reference defaults",
                        "gather": ("every_step" if gather_in_step else "after_loop")
                        if (world > 1 and not args.no_gather) else "none", "gather_ms": gather_ms,
-                       "gathered": ["x", "tau", "v", "status"], "reduced_stats": stats},
+                       # c4: mean per step of the solve (main stream) and of the collection (side stream, overlapping
+                       # the next step's solve); their sum is what a step would take without the overlap
+                       "step_solve_ms": step_solve_ms, "step_gather_ms": step_gather_ms,
+                       "step_solve_plus_gather_ms": (step_solve_ms + step_gather_ms) if step_solve_ms is not None else None,
+                       "outputs": sorted(k for k, v in out.items() if v is not None),
+                       "gathered": payload_keys if collector is not None else [], "reduced_stats": stats},
             # the fused entry's arithmetic intensity (~40 FLOP/B) is above the FP64 ridge, so the
             # nominal bound is FP64 vector throughput; HBM is reported beside it.  The kernel is in fact bound
             # by dependent-chain latency at one wave per SIMD.
             "roofline": {"bound": "fp64_vector", "achieved": ach_tf, "peak": FP64_VEC_PEAK_TF, "unit": "TFLOP/s",
                          "frac": ach_tf / FP64_VEC_PEAK_TF, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "hoqp_solve_kernel<GATE,HARD,WBC=true>", "kernel_ms": kern_ms,
+                         "kernel": "hoqp_solve_wbc_ref_kernel" if args.mode == "reference"
+                                   else "hoqp_solve_kernel<false,true,true>", "kernel_ms": kern_ms,
                          "launches_timed": kern_n, "alg_flops_per_solve": flops_mean,
                          "alg_bytes_per_solve": bytes_mean,
                          "hbm": {"achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -316,6 +316,47 @@ int hoqp_selftest(hoqp_handle *h);
 /* LDS bytes per workgroup the solve kernel needs for these extents (0 on error). */
 size_t hoqp_lds_bytes(int n, int num_levels, const int *m, const int *p);
 
+/*
+ * Multi-GPU host driver in ONE process.  No counterpart in the reference, which
+ * solves one state per cycle on one thread (whole_body_controller.cpp:329-342): the batch of independent states is
+ * cut into contiguous shards, one per GPU; every shard has its own worker thread, HIP stream and solver handle,
+ * so the shards' launches, copies and waits never serialise on one host thread.  There is no exchange step during
+ * the solve.  After it, optionally, (i) the per-instance results of every shard are copied device-to-device into
+ * arrays on a root GPU at the shard's offset (hipMemcpyPeerAsync on the shard's own stream: each peer uses its own
+ * xGMI link to the root -- the one-process form of the RCCL gather that bench.py's one-process-per-GPU path does) and
+ * (ii) the residual statistics are reduced on each device and combined on the host (MAX / SUM).
+ * devices[r] may repeat (several shards on one GPU: how the driver is tested on a one-GPU box).
+ */
+#define HOQP_MAX_SHARDS 16
+typedef struct hoqp_sharded hoqp_sharded;
+
+typedef struct {
+	double eq_res_max, ineq_viol_max;		  /* MAX over all instances and levels */
+	long long status_nonzero, iters_total, instances; /* SUM */
+} hoqp_shard_stats;
+
+typedef struct {
+	int root_device;  /* device that holds the collected arrays */
+	double *x;	  /* [total][30]  (any pointer may be NULL: not collected) */
+	double *tau;	  /* [total][12] */
+	double *v;	  /* [total][40] */
+	int *status;	  /* [total] */
+} hoqp_wbc_gather;
+
+int hoqp_sharded_create(const hoqp_config *cfg, int num_shards, const int *devices, hoqp_sharded **out);
+int hoqp_sharded_destroy(hoqp_sharded *s);
+const char *hoqp_sharded_last_error(const hoqp_sharded *s);
+
+/*
+ * Replaces: nothing in the reference (see above); per shard it is hoqp_solve_wbc_batched.  in[r] / out[r]
+ * (r < num_shards) hold device pointers ON devices[r]; in[r].batch is the shard's size (0 allowed).  Instance
+ * order of the collected arrays = shard order.  `gather` and `stats` may be NULL; statistics need
+ * out[r].eq_res_max, ineq_viol_max, status and iters.  Blocks until every shard, its copies and its statistics
+ * have completed.  Returns 0, or the first failing shard's error code (hoqp_sharded_last_error says which).
+ */
+int hoqp_solve_wbc_sharded(hoqp_sharded *s, const hoqp_wbc_inputs *in, const hoqp_wbc_outputs *out,
+			   const hoqp_wbc_gather *gather, hoqp_shard_stats *stats);
+
 #ifdef __cplusplus
 }
 #endif

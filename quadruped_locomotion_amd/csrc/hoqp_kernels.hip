@@ -14,6 +14,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1298,4 +1301,287 @@ extern "C" int hoqp_selftest(hoqp_handle *h)
 	if (host)
 		return fail(h, host, "wavefront primitive self-test failed, mask " + std::to_string(host));
 	return 0;
+}
+
+// ===========================================================================
+// Multi-GPU host driver in one process: one worker thread + stream + handle per shard (hoqp.h)
+// ===========================================================================
+namespace hoqp {
+
+// [0] max eq_res_max, [1] max ineq_viol_max as ordered-integer keys; [2] status != 0, [3] sum iters, [4] instances
+__device__ __forceinline__ unsigned long long dkey(double v)
+{
+	// monotone map double -> unsigned 64 (NaN sorts above +inf: a NaN residual must not be hidden by a max)
+	const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+	return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+__global__ void __launch_bounds__(256) shard_stats_kernel(int batch, const double *eq_res_max, const double *ineq_viol_max,
+							   const int *status, const int *iters, unsigned long long *acc)
+{
+	unsigned long long ke = 0ull, ki = 0ull, nbad = 0ull, nit = 0ull;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)batch; i += (size_t)gridDim.x * blockDim.x) {
+		for (int k = 0; k < 5; ++k) {
+			ke = max(ke, dkey(eq_res_max[i * 5 + k]));
+			ki = max(ki, dkey(ineq_viol_max[i * 5 + k]));
+			nit += (unsigned long long)iters[i * 5 + k];
+		}
+		nbad += status[i] != 0;
+	}
+	// wavefront reduction, then one atomic per wavefront
+	for (int off = 32; off > 0; off >>= 1) {
+		ke = max(ke, __shfl_xor(ke, off));
+		ki = max(ki, __shfl_xor(ki, off));
+		nbad += __shfl_xor(nbad, off);
+		nit += __shfl_xor(nit, off);
+	}
+	if ((threadIdx.x & 63) == 0) {
+		atomicMax(acc + 0, ke);
+		atomicMax(acc + 1, ki);
+		atomicAdd(acc + 2, nbad);
+		atomicAdd(acc + 3, nit);
+	}
+}
+
+}  // namespace hoqp
+
+namespace {
+double key_to_double(unsigned long long k)
+{
+	const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+	double v;
+	std::memcpy(&v, &b, sizeof(v));
+	return v;
+}
+
+struct ShardJob {
+	hoqp_wbc_inputs in;
+	hoqp_wbc_outputs out;
+	hoqp_wbc_gather gather;
+	bool do_gather = false, do_stats = false;
+	size_t offset = 0;  // instances before this shard
+};
+
+struct ShardWorker {
+	int device = 0;
+	hoqp_handle *h = nullptr;
+	hipStream_t stream = nullptr;
+	unsigned long long *acc_d = nullptr, *acc_h = nullptr;  // statistics: device accumulators, pinned host copy
+	std::thread th;
+	std::mutex m;
+	std::condition_variable cv;
+	ShardJob job;
+	bool has_job = false, done = false, quit = false;
+	int rc = 0;
+	std::string err;
+};
+}  // namespace
+
+struct hoqp_sharded {
+	std::vector<ShardWorker *> workers;
+	std::string err;
+};
+
+static int shard_run(ShardWorker *w)
+{
+	const ShardJob &j = w->job;
+	const int B = j.in.batch;
+	auto hipfail = [&](hipError_t e, const char *what) {
+		w->err = std::string(what) + ": " + hipGetErrorString(e);
+		return -3;
+	};
+#define SHIP(call)                                \
+	do {                                      \
+		hipError_t e_ = (call);           \
+		if (e_ != hipSuccess)             \
+			return hipfail(e_, #call); \
+	} while (0)
+	SHIP(hipSetDevice(w->device));
+	if (B > 0) {
+		const int rc = hoqp_solve_wbc_batched(w->h, &j.in, &j.out, w->stream);
+		if (rc) {
+			w->err = hoqp_last_error_string(w->h);
+			return rc;
+		}
+		if (j.do_gather) {
+			const int root = j.gather.root_device;
+			if (j.gather.x)
+				SHIP(hipMemcpyPeerAsync(j.gather.x + j.offset * 30, root, j.out.x, w->device, sizeof(double) * 30 * B, w->stream));
+			if (j.gather.tau && j.out.tau)
+				SHIP(hipMemcpyPeerAsync(j.gather.tau + j.offset * 12, root, j.out.tau, w->device, sizeof(double) * 12 * B, w->stream));
+			if (j.gather.v && j.out.v)
+				SHIP(hipMemcpyPeerAsync(j.gather.v + j.offset * 40, root, j.out.v, w->device, sizeof(double) * 40 * B, w->stream));
+			if (j.gather.status && j.out.status)
+				SHIP(hipMemcpyPeerAsync(j.gather.status + j.offset, root, j.out.status, w->device, sizeof(int) * B, w->stream));
+		}
+	}
+	if (j.do_stats) {
+		SHIP(hipMemsetAsync(w->acc_d, 0, 4 * sizeof(unsigned long long), w->stream));
+		if (B > 0) {
+			const int grid = std::min((B + 255) / 256, 1024);
+			hipLaunchKernelGGL(hoqp::shard_stats_kernel, dim3(grid), dim3(256), 0, w->stream, B, j.out.eq_res_max,
+					   j.out.ineq_viol_max, j.out.status, j.out.iters, w->acc_d);
+			SHIP(hipGetLastError());
+		}
+		SHIP(hipMemcpyAsync(w->acc_h, w->acc_d, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, w->stream));
+	}
+	SHIP(hipStreamSynchronize(w->stream));
+#undef SHIP
+	return 0;
+}
+
+static void shard_loop(ShardWorker *w)
+{
+	for (;;) {
+		std::unique_lock<std::mutex> lk(w->m);
+		w->cv.wait(lk, [&] { return w->has_job || w->quit; });
+		if (w->quit)
+			return;
+		w->has_job = false;
+		lk.unlock();
+		const int rc = shard_run(w);
+		lk.lock();
+		w->rc = rc;
+		w->done = true;
+		lk.unlock();
+		w->cv.notify_all();
+	}
+}
+
+extern "C" int hoqp_sharded_destroy(hoqp_sharded *s)
+{
+	if (!s)
+		return -1;
+	for (ShardWorker *w : s->workers) {
+		if (w->th.joinable()) {
+			{
+				std::lock_guard<std::mutex> lk(w->m);
+				w->quit = true;
+			}
+			w->cv.notify_all();
+			w->th.join();
+		}
+		if (w->stream || w->acc_d || w->acc_h) {  // (a worker whose handle could not be created owns nothing)
+			int prev = -1;
+			(void)hipGetDevice(&prev);
+			if (hipSetDevice(w->device) == hipSuccess) {
+				if (w->stream)
+					(void)hipStreamDestroy(w->stream);
+				if (w->acc_d)
+					(void)hipFree(w->acc_d);
+				if (w->acc_h)
+					(void)hipHostFree(w->acc_h);
+			}
+			if (prev >= 0)
+				(void)hipSetDevice(prev);
+		}
+		if (w->h)
+			(void)hoqp_destroy(w->h);
+		delete w;
+	}
+	delete s;
+	return 0;
+}
+
+extern "C" int hoqp_sharded_create(const hoqp_config *cfg, int num_shards, const int *devices, hoqp_sharded **out)
+{
+	if (!cfg || !devices || !out || num_shards < 1 || num_shards > HOQP_MAX_SHARDS)
+		return -1;
+	hoqp_sharded *s = new hoqp_sharded();
+	int prev = -1;
+	(void)hipGetDevice(&prev);
+	int rc = 0;
+	for (int r = 0; r < num_shards && rc == 0; ++r) {
+		ShardWorker *w = new ShardWorker();
+		s->workers.push_back(w);
+		w->device = devices[r];
+		hoqp_config c = *cfg;
+		c.device = devices[r];
+		rc = hoqp_create(&c, &w->h);
+		if (rc)
+			break;
+		if (hipSetDevice(w->device) != hipSuccess || hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess ||
+		    hipMalloc(&w->acc_d, 4 * sizeof(unsigned long long)) != hipSuccess ||
+		    hipHostMalloc(&w->acc_h, 4 * sizeof(unsigned long long)) != hipSuccess) {
+			rc = -3;
+			break;
+		}
+		w->th = std::thread(shard_loop, w);
+	}
+	if (prev >= 0)
+		(void)hipSetDevice(prev);
+	if (rc) {
+		hoqp_sharded_destroy(s);
+		return rc;
+	}
+	*out = s;
+	return 0;
+}
+
+extern "C" const char *hoqp_sharded_last_error(const hoqp_sharded *s) { return s ? s->err.c_str() : "null handle"; }
+
+extern "C" int hoqp_solve_wbc_sharded(hoqp_sharded *s, const hoqp_wbc_inputs *in, const hoqp_wbc_outputs *out,
+				      const hoqp_wbc_gather *gather, hoqp_shard_stats *stats)
+{
+	if (!s)
+		return -1;
+	if (!in || !out) {
+		s->err = "null argument";
+		return -1;
+	}
+	const size_t R = s->workers.size();
+	size_t off = 0;
+	for (size_t r = 0; r < R; ++r) {
+		if (in[r].batch < 0 || (in[r].batch > 0 && !out[r].x)) {
+			s->err = "shard " + std::to_string(r) + ": negative batch or no x output";
+			return -1;
+		}
+		if (stats && in[r].batch > 0 && !(out[r].eq_res_max && out[r].ineq_viol_max && out[r].status && out[r].iters)) {
+			s->err = "shard " + std::to_string(r) + ": statistics need eq_res_max, ineq_viol_max, status and iters";
+			return -1;
+		}
+	}
+	for (size_t r = 0; r < R; ++r) {
+		ShardWorker *w = s->workers[r];
+		{
+			std::lock_guard<std::mutex> lk(w->m);
+			w->job.in = in[r];
+			w->job.out = out[r];
+			w->job.do_gather = gather != nullptr;
+			if (gather)
+				w->job.gather = *gather;
+			w->job.do_stats = stats != nullptr;
+			w->job.offset = off;
+			w->done = false;
+			w->has_job = true;
+		}
+		w->cv.notify_all();
+		off += (size_t)in[r].batch;
+	}
+	int rc = 0;
+	hoqp_shard_stats acc = {-1e300, -1e300, 0, 0, 0};
+	for (size_t r = 0; r < R; ++r) {
+		ShardWorker *w = s->workers[r];
+		std::unique_lock<std::mutex> lk(w->m);
+		w->cv.wait(lk, [&] { return w->done; });
+		if (w->rc && !rc) {
+			rc = w->rc;
+			s->err = "shard " + std::to_string(r) + " (device " + std::to_string(w->device) + "): " + w->err;
+		}
+		if (stats && !w->rc && in[r].batch > 0) {
+			const double e = key_to_double(w->acc_h[0]), v = key_to_double(w->acc_h[1]);
+			// a NaN on any shard stays visible (std::max would drop it)
+			acc.eq_res_max = (e != e || acc.eq_res_max != acc.eq_res_max) ? NAN : std::max(acc.eq_res_max, e);
+			acc.ineq_viol_max = (v != v || acc.ineq_viol_max != acc.ineq_viol_max) ? NAN : std::max(acc.ineq_viol_max, v);
+			acc.status_nonzero += (long long)w->acc_h[2];
+			acc.iters_total += (long long)w->acc_h[3];
+			acc.instances += in[r].batch;
+		}
+	}
+	if (stats) {
+		if (acc.instances == 0)
+			acc.eq_res_max = acc.ineq_viol_max = 0.0;
+		*stats = acc;
+	}
+	return rc;
 }

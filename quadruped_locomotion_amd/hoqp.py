@@ -42,7 +42,9 @@ EXPORTS = (
     "hoqp_default_gait", "hoqp_gait_sample_batched", "hoqp_standup_sample_batched",
     "hoqp_base_walk_sample_batched", "hoqp_synchronize",
     "hoqp_kernel_time_ms", "hoqp_selftest", "hoqp_lds_bytes",
+    "hoqp_sharded_create", "hoqp_sharded_destroy", "hoqp_sharded_last_error", "hoqp_solve_wbc_sharded",
 )
+MAX_SHARDS = 16
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -97,6 +99,16 @@ class WbcOutputs(C.Structure):
                 ("iters", C.c_void_p), ("nz_levels", C.c_void_p), ("x_levels", C.c_void_p)]
 
 
+class ShardStats(C.Structure):
+    _fields_ = [("eq_res_max", C.c_double), ("ineq_viol_max", C.c_double), ("status_nonzero", C.c_longlong),
+                ("iters_total", C.c_longlong), ("instances", C.c_longlong)]
+
+
+class WbcGather(C.Structure):
+    _fields_ = [("root_device", C.c_int), ("x", C.c_void_p), ("tau", C.c_void_p), ("v", C.c_void_p),
+                ("status", C.c_void_p)]
+
+
 _lib = None
 
 
@@ -141,6 +153,12 @@ def load_library():
         lib.hoqp_selftest.argtypes = [C.c_void_p]
         lib.hoqp_lds_bytes.argtypes = [C.c_int, C.c_int, _ip, _ip]
         lib.hoqp_lds_bytes.restype = C.c_size_t
+        lib.hoqp_sharded_create.argtypes = [C.POINTER(Config), C.c_int, _ip, C.POINTER(C.c_void_p)]
+        lib.hoqp_sharded_destroy.argtypes = [C.c_void_p]
+        lib.hoqp_sharded_last_error.argtypes = [C.c_void_p]
+        lib.hoqp_sharded_last_error.restype = C.c_char_p
+        lib.hoqp_solve_wbc_sharded.argtypes = [C.c_void_p, C.POINTER(WbcInputs), C.POINTER(WbcOutputs),
+                                               C.POINTER(WbcGather), C.POINTER(ShardStats)]
         _lib = lib
     return _lib
 
@@ -479,3 +497,64 @@ class HoQpSolver:
             setattr(wo, name, arr.ctypes.data)
         self._check(self.lib.hoqp_solve_wbc_host(self.h, C.byref(wi), C.byref(wo)), "hoqp_solve_wbc_host")
         return out
+
+
+class ShardedSolver:
+    """hoqp_sharded_*: the one-process multi-GPU driver (one worker thread + stream + handle per shard).
+    `devices`: HIP ordinal of every shard (may repeat)."""
+
+    def __init__(self, cfg: Config, devices):
+        import torch
+
+        self.lib = load_library()
+        self.torch = torch
+        self.devices = list(devices)
+        self.cfg = cfg
+        h = C.c_void_p()
+        rc = self.lib.hoqp_sharded_create(C.byref(cfg), len(self.devices), (C.c_int * len(self.devices))(*self.devices),
+                                          C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"hoqp_sharded_create failed: {rc}")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.hoqp_sharded_destroy(self.h)
+            self.h = None
+
+    def solve_wbc(self, shards_in, shards_out, gather=None, want_stats=True):
+        """shards_in / shards_out: one dict of device tensors per shard (as HoQpSolver.solve_wbc takes; a shard
+        may be None: empty).  gather: dict with "device" and optional x / tau / v / status tensors of the total
+        size on that device.  Returns the reduced statistics (or None).  Blocks until done."""
+        t = self.torch
+        R = len(self.devices)
+        assert len(shards_in) == R and len(shards_out) == R
+        wi, wo = (WbcInputs * R)(), (WbcOutputs * R)()
+        for r in range(R):
+            if shards_in[r] is None:
+                continue
+            d = shards_in[r]
+            wi[r].batch = d["M"].shape[0]
+            for name in ("M", "h", "Jfoot", "Jdotu", "footpos", "Jb", "q", "u", "base_cmd", "leg_cmd", "contact"):
+                arr = d.get(name)
+                if arr is not None:
+                    assert arr.is_contiguous() and arr.is_cuda and arr.device.index == self.devices[r], name
+                    setattr(wi[r], name, arr.data_ptr())
+            for name, _ in WbcOutputs._fields_:
+                if shards_out[r].get(name) is not None:
+                    setattr(wo[r], name, shards_out[r][name].data_ptr())
+        g = None
+        if gather is not None:
+            g = WbcGather()
+            g.root_device = gather["device"]
+            for name in ("x", "tau", "v", "status"):
+                if gather.get(name) is not None:
+                    setattr(g, name, gather[name].data_ptr())
+        st = ShardStats() if want_stats else None
+        t.cuda.synchronize()     # inputs written on torch streams are complete before the worker streams read them
+        rc = self.lib.hoqp_solve_wbc_sharded(self.h, wi, wo, C.byref(g) if g is not None else None,
+                                             C.byref(st) if st is not None else None)
+        if rc != 0:
+            msg = self.lib.hoqp_sharded_last_error(self.h)
+            raise RuntimeError(f"hoqp_solve_wbc_sharded failed ({rc}): {msg.decode() if msg else ''}")
+        return st

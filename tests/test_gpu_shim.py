@@ -110,10 +110,15 @@ def test_bench_two_rank_rehearsal():
     import json
     import sys
 
+    import socket
+
     root = os.path.dirname(HERE)
+    with socket.socket() as sk:                       # a free port, not a fixed one
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     env = dict(os.environ, HOQP_BENCH_REHEARSE="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "c4", "--batch", "8191",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "c4", "--batch", "8191",
            "--steps", "3", "--warmup", "1", "--latency-batches", "5"]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert res.returncode == 0, res.stderr[-2000:]
@@ -124,6 +129,11 @@ def test_bench_two_rank_rehearsal():
     st = d["config"]["reduced_stats"]
     assert st["instances"] == 8191 and st["status_nonzero"] == 0 and np.isfinite(st["eq_res_max"])
     assert d["value"] > 0 and d["config"]["gather_ms"] > 0
+    # the collection is reported separately from the solve, per step, and summed
+    c = d["config"]
+    assert c["step_solve_ms"] > 0 and c["step_gather_ms"] > 0
+    assert abs(c["step_solve_plus_gather_ms"] - (c["step_solve_ms"] + c["step_gather_ms"])) < 1e-9
+    assert c["gathered"] == ["x", "tau", "v", "status"] and "x_levels" not in c["outputs"]
 
 
 def test_bench_pipelined_option():

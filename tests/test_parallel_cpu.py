@@ -44,10 +44,25 @@ def _worker(rank, world, port, total, tmp):
     # the payload of SURVEY.md 8(e): x, tau, v*, status
     full = parallel.gather_solutions(dict(x=local["x"], tau=local["tau"], v=local["v"], status=local["status"]),
                                      total, dst=0)
+    # the persistent collector the benchmark uses: destination allocated once, two buffer sets, two steps whose
+    # payloads differ (step 1 sends the negated x), received straight into the slices of rank 0's arrays
+    payload = dict(x=local["x"], tau=local["tau"], v=local["v"], status=local["status"])
+    col = parallel.ResultCollector({k: (tuple(v.shape[1:]), v.dtype) for k, v in payload.items()}, total, "cpu",
+                                   dst=0, buffers=2)
+    r0 = col.start(payload, 0)
+    r1 = col.start(dict(payload, x=-payload["x"]), 1)
+    col.wait(r0)
+    col.wait(r1)
+    ptrs = None
     if rank == 0:
-        torch.save(dict(full=full, mx=mx, sm=sm), os.path.join(tmp, "out.pt"))
+        ptrs = [col.slot(i)["x"].data_ptr() for i in (0, 1)]
+        col.collect(payload, 2)                      # buffer set 2 == buffer set 0: reused, not reallocated
+        assert [col.slot(i)["x"].data_ptr() for i in (0, 1)] == ptrs and col.slot(2)["x"].data_ptr() == ptrs[0]
+        torch.save(dict(full=full, mx=mx, sm=sm, c0={k: v.clone() for k, v in col.slot(0).items()},
+                        c1x=col.slot(1)["x"].clone()), os.path.join(tmp, "out.pt"))
     else:
-        assert full is None
+        col.collect(payload, 2)
+        assert full is None and col.slot(0) is None
     dist.barrier()
     dist.destroy_process_group()
 
@@ -87,3 +102,6 @@ def test_two_rank_gather_and_stats(tmp_path, total):
     assert abs(got["mx"][1].item() - ref["ineq_viol_max"].max()) < 1e-15
     assert got["sm"][0].item() == (ref["status"] != 0).sum()
     assert got["sm"][2].item() == total and got["sm"][1].item() == ref["iters"].sum()
+    for key in ("x", "tau", "v", "status"):
+        assert torch.equal(got["c0"][key], got["full"][key]), key
+    assert np.array_equal(got["c1x"].numpy(), -ref["x"])

@@ -44,3 +44,34 @@ def test_noalloc_entry_rejects_oversize(solver_factory):
     d = s.to_device(am.make_wbc_inputs(am.sample_states(hoqp.NOALLOC_MAX_BATCH + 1, 43, "stance")))
     with pytest.raises(RuntimeError, match="HOQP_NOALLOC_MAX_BATCH"):
         s.solve_wbc(d, entry="noalloc")
+
+
+def test_noalloc_entry_under_graph_capture(solver_factory):
+    """The claim of include/hoqp.h that the entry can be issued under HIP graph capture: two calls are captured
+    into one graph (torch.cuda.graph drives hipStreamBeginCapture / EndCapture on the capture stream that the
+    entry is given), the graph is replayed after the inputs changed in place, and the outputs must be those of
+    the eager entry on the new inputs.  A hipMalloc / hipFree / synchronisation inside the entry would make the
+    capture fail."""
+    import torch
+
+    s = solver_factory("reference")
+    inp_a = am.make_wbc_inputs(am.sample_states(64, 44, "trot"))
+    inp_b = am.make_wbc_inputs(am.sample_states(64, 45, "trot"))
+    d = s.to_device(inp_a)
+    out1, out2 = s.alloc_wbc_outputs(64), s.alloc_wbc_outputs(64)
+    s.solve_wbc(d, out1, entry="noalloc")          # first use outside the capture (module load, attributes)
+    s.synchronize()
+    g = torch.cuda.CUDAGraph()
+    cap = torch.cuda.Stream()
+    with torch.cuda.graph(g, stream=cap):
+        s.solve_wbc(d, out1, entry="noalloc")
+        s.solve_wbc(d, out2, entry="noalloc")      # second call in the same graph, same scratch: serialised by the stream
+    for k, v in s.to_device(inp_b).items():
+        d[k].copy_(v)                              # new inputs at the captured addresses
+    g.replay()
+    torch.cuda.synchronize()
+    want = {k: v.cpu().numpy() for k, v in s.solve_wbc(d, entry="unfused").items()}
+    s.synchronize()
+    for o in (out1, out2):
+        for key in ("x", "tau", "v", "flags", "status"):
+            assert np.array_equal(o[key].cpu().numpy(), want[key]), key

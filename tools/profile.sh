@@ -17,6 +17,8 @@ pmc sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS S
 pmc sq2 SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT
 pmc sqc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES
 cd $ROOT
+# what FETCH_SIZE / WRITE_SIZE report for this kernel's access pattern (factors applied by the summary)
+bash tools/calib/fetch_calib.sh > gpurun_out/rocprof/calib.log 2>&1 || echo "calibration failed"
 python3 tools/profile_summarize.py gpurun_out/rocprof gpurun_out/rocprof/summary
 # full bench line (with the CPU baseline) and the per-section cycle profile of the profiling build
 timeout -k 10 400 python3 bench.py > gpurun_out/rocprof/bench_full.json
