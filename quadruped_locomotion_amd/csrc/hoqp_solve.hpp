@@ -26,12 +26,16 @@ constexpr int LDV = 34;	  // leading dimension of the reflector store
 constexpr int SROW = 36;  // row stride of the task staging buffer of the n_z == 32 projection (16-byte
 			  // aligned rows); the matrix-core projection loads its operand from global memory
 constexpr int XROWS = 16; // dumped unpivoted columns (rank-deficient least squares); aliases S
-// Compact LDS layout of the fused WBC kernel under reference semantics (SolveArgs::compact; 26,344 B per
-// workgroup: six workgroups per CU instead of four).  It rests on two facts of that hierarchy: level 0 never
-// stores Z = I (its rotation generates the rows) and leaves n - 6 <= 24 free coordinates, so from level 1 on
-// every vector handled has at most 24 entries -- Z, G, the dependent-column store and the projected task rows
-// take a leading dimension of 25, the reflector store 25 (level 0, whose six reflectors have 30 entries: 34);
-// and at most 8 dependent columns are kept for a rank-deficient least squares (more: HOQP_STATUS_WORKSPACE).
+// Compact LDS layout of the fused WBC kernel under reference semantics (SolveArgs::compact; 19,824 B per
+// workgroup: eight workgroups per CU -- two waves on every SIMD -- instead of four).  It rests on these facts of
+// that hierarchy: level 0 never stores Z = I (its rotation generates the rows) and leaves n - 6 <= 24 free
+// coordinates, so from level 1 on every vector handled has at most 24 entries -- Z, G, the dependent-column
+// store and the projected task rows take a leading dimension of 25, the reflector store 25 (level 0, whose six
+// reflectors have 30 entries: 34); of the 40 inequality rows of level 1 only the 12 torque rows are stored, the
+// negated copies and the friction rows (two non-zeros each) are formed from G and Z on the fly (vrow); the
+// level-1 QP has no least-squares rows and no working set (Q2), so BL / r0 / rho / a0 are stubs; at most 8
+// dependent columns are kept for a rank-deficient least squares (more: HOQP_STATUS_WORKSPACE); and the
+// reference replay updates its basis chain in place inside G + TV + S.
 // A state whose floating-base block [M_fb, -J_c,fb^T] has rank < 6 (impossible for a physical mass matrix) does
 // not fit and is reported as HOQP_STATUS_BASE_RANK instead of being solved.
 constexpr int kCLd = 25;	 // Z, G, X, projected rows of levels >= 1
@@ -39,7 +43,8 @@ constexpr int kCLd0 = 31;	 // projected rows of level 0 (6 x n)
 constexpr int kCLdv = 25;	 // reflector store, levels >= 1
 constexpr int kCXrows = 8;	 // dependent-column store
 constexpr int kCTv = 24 * kCLdv + 8;	 // >= 6 * LDV, >= 18 * kCLd: reflector store / projected rows
-constexpr int kCReplayZ = 1100;	 // replay: doubles for the chain of bases (30 x 24 + 30 x 12), rest: M and K
+constexpr int kCGrows = 12;	 // stored rows of G (= kNJ torque rows)
+constexpr int kCReplayZ = 720;	 // replay: doubles for the basis (30 x 24, updated in place), rest: M and its factors
 constexpr int CHUNK = 16; // task rows per projection pass (one 16 x K matrix-core operand tile)
 constexpr int kDbgSlots = 56;	  // HOQP_PROFILE builds: cycle-stamp slots per instance
 // the reference replay runs when eps / (smallest pivot)^2 of an unconstrained level exceeds this
@@ -104,7 +109,7 @@ __host__ __device__ inline LdsOff lds_offsets(const SolveArgs &a)
 	if (a.compact) {
 		// G, TV and S are contiguous: the reference replay uses them as one scratch region, and reads
 		// of a masked-off tail of a TV row (tall levels: 32 rows x ld) stay inside the allocation
-		o.G = take(8 * P * ld);
+		o.G = take(8 * kCGrows * ld);
 		o.TV = take(8 * kCTv);
 		o.S = take(8 * kCXrows * ld);
 	}
@@ -117,10 +122,10 @@ __host__ __device__ inline LdsOff lds_offsets(const SolveArgs &a)
 		o.TV = take(8 * tv);
 		o.S = take(8 * ((CHUNK * SROW > XROWS * ld) ? CHUNK * SROW : XROWS * ld));
 	}
-	o.BL = take(8 * ((mm && a.use_bl) ? mm : 1) * ld);
-	o.r0 = take(8 * (mm + 1));
-	o.rho = take(8 * (mm + 1));
-	o.a0 = take(8 * (mm + 1));
+	o.BL = take(a.compact ? 16 : 8 * ((mm && a.use_bl) ? mm : 1) * ld);
+	o.r0 = take(a.compact ? 16 : 8 * (mm + 1));
+	o.rho = take(a.compact ? 16 : 8 * (mm + 1));
+	o.a0 = take(a.compact ? 16 : 8 * (mm + 1));
 	o.tau = take(8 * NR);
 	o.rdiag = take(8 * NR);
 	o.rhs = take(8 * kWave);
@@ -130,7 +135,7 @@ __host__ __device__ inline LdsOff lds_offsets(const SolveArgs &a)
 	o.b3 = take(8 * 24);	   // fused WBC entry: right-hand side of the tracking level
 	o.pivlane = take(4 * NR);
 	o.W = take(4 * NR);
-	o.xlane = take(4 * XROWS);  // (compact: kCXrows used)
+	o.xlane = take(4 * (a.compact ? kCXrows : XROWS));
 	o.colpos = take(4 * kWave);
 	o.vlist = take(4 * kWave);
 	o.total = off + 256;  // readable tail: full-width (NR) vector reads may run past the last array
@@ -184,7 +189,7 @@ __device__ __forceinline__ Lds lds_bind(const SolveArgs &a, HOQP_LDS char *base)
 		l.rpZ = l.G;
 		l.rpZcap = kCReplayZ;
 		l.rpM = l.G + kCReplayZ;
-		l.rpMcap = a.Ptot * kCLd + kCTv + kCXrows * kCLd - kCReplayZ;
+		l.rpMcap = kCGrows * kCLd + kCTv + kCXrows * kCLd - kCReplayZ;
 	} else {
 		l.rpZ = l.G;
 		l.rpZcap = (a.Ptot ? a.Ptot : 1) * a.ld;
@@ -644,6 +649,82 @@ __device__ __forceinline__ void rows_dot(const ldsd *A, int R, int ldr, int nr, 
 		double d0 = 0.0, d1 = 0.0;
 		t_upto(nr, s, [&](int t, bool on) {
 			const double e = sel(on, ev[sl][t]);
+			if (t & 1)
+				d1 = fma(e, vv[t], d1);
+			else
+				d0 = fma(e, vv[t], d0);
+		});
+		const double d = quad_sum(d0 + d1);
+		if (r < R && s == 0)
+			out[r] = d;
+	}
+}
+
+// ---------------------------------------------------------------------------
+// Virtual rows of the torque / friction block (level 1 of the fused reference kernel, compact layout).  Of its
+// 24 + 4 n_c projected rows only the 12 torque rows [M_j, -J_c,j^T] Z are stored (l.G); the others are
+//   rows 12..23 : the negated rows 0..11                         (ConstructJointTorqueTask, [D; -D])
+//   rows 24..   : +-Z[col + (t >> 1)] - mu Z[col + 2]            (ConstructFrictionConeTask, two non-zeros per row)
+// i.e. every row is  s0 * p0[j] + s1 * p1[j]  over rows p0, p1 of l.G or l.Z -- formed on the fly with one
+// multiplication by +-1 (exact) and one FMA, bit-identical to the rows wbc_project_level1 used to store.
+// Z is not touched while level 1 runs (no equality rows: no rotation), so the rows stay valid.
+// ---------------------------------------------------------------------------
+struct VRowCtx {
+	const ldsd *G, *Z;
+	int ld, clp, nc, quirk;
+	double mu;
+};
+struct VRow {
+	const ldsd *p0, *p1;
+	double s0, s1;
+};
+__device__ __forceinline__ VRow vrow(const VRowCtx &v, int r)
+{
+	VRow o;
+	const int rr = (r < kNJ) ? r : r - kNJ;
+	const int f = (r >= 2 * kNJ) ? r - 2 * kNJ : 0;
+	const int i = f >> 2, t = f & 3;
+	const int col = v.quirk ? kNB + wbc_pick(v.clp, i) * 3 : kNU + 3 * i;
+	const bool tq = r < 2 * kNJ;
+	o.p0 = tq ? v.G + (rr < kNJ ? rr : 0) * v.ld : v.Z + (col + (t >> 1)) * v.ld;
+	o.p1 = tq ? o.p0 : v.Z + (col + 2) * v.ld;
+	o.s0 = tq ? ((r < kNJ) ? 1.0 : -1.0) : ((t & 1) ? -1.0 : 1.0);
+	o.s1 = tq ? 0.0 : 0.0 - v.mu;
+	return o;
+}
+__device__ __forceinline__ double vval(const VRow &r, double a, double b) { return fma(r.s1, b, r.s0 * a); }
+
+// rows_dot over the virtual rows: out[r] = row_r[0..nr) . vec[0..nr) for r < R
+template <int NS>
+__device__ __forceinline__ void rows_dot_v(const VRowCtx &vc, int R, int nr, const ldsd *vec, ldsd *out)
+{
+	const int lane = lane_id(), s = lane & 3, c = lane >> 2;
+	if (R <= 0)
+		return;
+	double vv[NT];
+	double ea[NS][NT], eb[NS][NT];
+	VRow vr[NS];
+	ld8(vv, vec + s);
+#pragma unroll
+	for (int sl = 0; sl < NS; ++sl) {
+		const int r = c + 16 * sl;
+		vr[sl] = vrow(vc, r < R ? r : 0);
+		ld8(ea[sl], vr[sl].p0 + s);
+		ld8(eb[sl], vr[sl].p1 + s);
+	}
+	pin8(vv);
+#pragma unroll
+	for (int sl = 0; sl < NS; ++sl) {
+		pin8(ea[sl]);
+		pin8(eb[sl]);
+	}
+	t_upto(nr, s, [&](int t, bool on) { vv[t] = sel(on, vv[t]); });
+#pragma unroll
+	for (int sl = 0; sl < NS; ++sl) {
+		const int r = c + 16 * sl;
+		double d0 = 0.0, d1 = 0.0;
+		t_upto(nr, s, [&](int t, bool on) {
+			const double e = sel(on, vval(vr[sl], ea[sl][t], eb[sl][t]));
 			if (t & 1)
 				d1 = fma(e, vv[t], d1);
 			else
@@ -1483,6 +1564,8 @@ __device__ __forceinline__ void wbc_project_level0(const WbcCtx &wx, int ld, con
 //   rows 12..23  the negated rows 0..11        written as the negated results (exact)
 //   rows 24..    friction pyramid, two non-zeros per row: +-Z[col + (t >> 1)] - mu Z[col + 2], straight from Z
 // Same values as the generated rows of wbc_entry<1> pushed through project_task_mfma.
+// VG: only the 12 torque rows and every right-hand side are stored; the other rows are virtual (see vrow).
+template <bool VG = false>
 __device__ __forceinline__ void wbc_project_level1(const WbcCtx &wx, const WbcPrm &prm, const int (&jc)[NR / 4], int nz, int ld,
 						   const double (&bm)[NR / 4][2], const ProjDst dst, const Lds &l)
 {
@@ -1549,7 +1632,7 @@ __device__ __forceinline__ void wbc_project_level1(const WbcCtx &wx, const WbcPr
 	// friction rows while the matrix cores work
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {
-		const bool on = i < wx.nc && (fz || fx);
+		const bool on = i < wx.nc && (VG ? fx : (fz || fx));
 		const double vp = fma(-prm.mu, fc[i], fa[i]), vm = fma(-prm.mu, fc[i], 0.0 - fa[i]);
 		const int row = 2 * kNJ + 4 * i + 2 * hf;
 		ldsd *d0 = fz ? dst.M + row * dst.ldm + fj : dst.rhs + row;
@@ -1573,7 +1656,7 @@ __device__ __forceinline__ void wbc_project_level1(const WbcCtx &wx, const WbcPr
 			ldsd *du = isZ ? dst.M + i * dst.ldm + j : dst.rhs + i;
 			ldsd *dl = isZ ? dst.M + (kNJ + i) * dst.ldm + j : dst.rhs + kNJ + i;
 			st_if(isZ || isX, du, l.dump + lane, isX ? fu - v : v);
-			st_if(isZ || isX, dl, l.dump + lane, isX ? fl + v : 0.0 - v);
+			st_if(VG ? isX : (isZ || isX), dl, l.dump + lane, isX ? fl + v : 0.0 - v);
 		}
 	}
 	wave_sync();
@@ -1625,9 +1708,10 @@ __device__ __forceinline__ int unp_index(bool unp, int &base)
 //   [ G_W' | B0' | G_V' ]  (w + m + |V| <= 64 columns, rows of V listed in l.vlist).
 // Returns p_i in lane i; *k1_out = rank of the working set (reflectors [0,k1) stay in TV).
 // ---------------------------------------------------------------------------
-template <bool HARD, bool VL = false>
+// VG: the rows of G are virtual (vrow; the fused reference kernel's level 1: no working set, no LS rows)
+template <bool HARD, bool VL = false, bool VG = false>
 __device__ __forceinline__ double eqp_step(const SolveArgs &a, const Lds &l, LevelState &st, int ld, int nz, int rank, int m,
-				  int w_in, int nV, int *k1_out, bool *overflow)
+				  int w_in, int nV, int *k1_out, bool *overflow, const VRowCtx &vc)
 {
 	const int w = HARD ? w_in : 0;  // no stored hard rows: the working set is always empty
 	const int lane = lane_id(), s = lane & 3, c = lane >> 2;
@@ -1640,6 +1724,8 @@ __device__ __forceinline__ double eqp_step(const SolveArgs &a, const Lds &l, Lev
 	}
 	const int nslot = (ncol + 15) >> 4;
 	double x[NSP][NT];
+	double xb[VG ? NSP : 1][NT];
+	VRow vrs[VG ? NSP : 1];
 	int pos[NSP], lims[NSP];
 	wave_sync();
 #pragma unroll
@@ -1654,9 +1740,15 @@ __device__ __forceinline__ double eqp_step(const SolveArgs &a, const Lds &l, Lev
 		const int wq = l.W[isW ? q : 0];
 		const int vq = l.vlist[(has && !isW && !isL) ? q - w - m : 0];
 		const int grow = has ? (isW ? wq : (isL ? 0 : vq)) : 0;
-		const ldsd *src = isL ? l.BL + (q - w) * ld : l.G + grow * ld;
 		lims[sl] = has ? (isL ? rank : nz) : 0;
-		ld8(x[sl], src + s);
+		if (VG) {
+			vrs[sl] = vrow(vc, grow);
+			ld8(x[sl], vrs[sl].p0 + s);
+			ld8(xb[sl], vrs[sl].p1 + s);
+		} else {
+			const ldsd *src = isL ? l.BL + (q - w) * ld : l.G + grow * ld;
+			ld8(x[sl], src + s);
+		}
 		pos[sl] = has ? -1 : -2;
 	}
 #pragma unroll
@@ -1664,6 +1756,12 @@ __device__ __forceinline__ double eqp_step(const SolveArgs &a, const Lds &l, Lev
 		if (sl >= nslot)
 			continue;
 		pin8(x[sl]);
+		if (VG) {
+			pin8(xb[sl]);
+#pragma unroll
+			for (int t = 0; t < NT; ++t)
+				x[sl][t] = vval(vrs[sl], x[sl][t], xb[sl][t]);
+		}
 		t_upto(nz, s, [&](int t, bool) { x[sl][t] = sel(s + 4 * t < lims[sl], x[sl][t]); });
 	}
 	{
@@ -1741,19 +1839,49 @@ __device__ __forceinline__ double eqp_step(const SolveArgs &a, const Lds &l, Lev
 // Squaring the condition number is harmless while it is small: accepted only if the smallest pivot is above
 // 1e-4 of the largest diagonal entry (kappa(G_V) < 100); otherwise (dependent or nearly dependent rows)
 // the caller factors as usual.  Returns false in that case.
-__device__ __forceinline__ bool eqp_dual8(const Lds &l, int nz, int nV, int ld, double *p_out)
+template <bool VG = false>
+__device__ __forceinline__ bool eqp_dual8(const Lds &l, int nz, int nV, int ld, double *p_out, const VRowCtx &vc)
 {
 	const int lane = lane_id(), gi = lane >> 3, gj = lane & 7;
 	const int ri = l.vlist[gi < nV ? gi : 0], rj = l.vlist[gj < nV ? gj : 0];
-	const ldsd *ra = l.G + ri * ld, *rb = l.G + rj * ld;
+	const ldsd *ra = l.G + (VG ? 0 : ri) * ld, *rb = l.G + (VG ? 0 : rj) * ld;
+	VRow va = {}, vb = {};
+	if (VG) {
+		va = vrow(vc, ri);
+		vb = vrow(vc, rj);
+	}
 	double g0 = 0.0, g1 = 0.0;
 	for (int k0 = 0; k0 < nz; k0 += 8) {
 		double av[8], bv[8];
+		if (VG) {
+			double a1[8], b1[8];
 #pragma unroll
-		for (int u = 0; u < 8; ++u) {
-			const int kk = (k0 + u < nz) ? k0 + u : 0;
-			av[u] = ra[kk];
-			bv[u] = rb[kk];
+			for (int u = 0; u < 8; ++u) {
+				const int kk = (k0 + u < nz) ? k0 + u : 0;
+				av[u] = va.p0[kk];
+				a1[u] = va.p1[kk];
+				bv[u] = vb.p0[kk];
+				b1[u] = vb.p1[kk];
+			}
+#pragma unroll
+			for (int u = 0; u < 8; ++u) {
+				pin(av[u]);
+				pin(a1[u]);
+				pin(bv[u]);
+				pin(b1[u]);
+			}
+#pragma unroll
+			for (int u = 0; u < 8; ++u) {
+				av[u] = vval(va, av[u], a1[u]);
+				bv[u] = vval(vb, bv[u], b1[u]);
+			}
+		} else {
+#pragma unroll
+			for (int u = 0; u < 8; ++u) {
+				const int kk = (k0 + u < nz) ? k0 + u : 0;
+				av[u] = ra[kk];
+				bv[u] = rb[kk];
+			}
 		}
 #pragma unroll
 		for (int u = 0; u < 8; ++u) {
@@ -1781,9 +1909,28 @@ __device__ __forceinline__ bool eqp_dual8(const Lds &l, int nz, int nV, int ld, 
 	// p_k = sum_i G[v_i][k] lam_i, one coordinate per lane
 	const int kk = lane < nz ? lane : 0;
 	double gk[8];
+	if (VG) {
+		double g1[8];
+		VRow vr[8];
 #pragma unroll
-	for (int i = 0; i < 8; ++i)
-		gk[i] = l.G[__builtin_amdgcn_readlane(ri, 8 * i) * ld + kk];
+		for (int i = 0; i < 8; ++i) {
+			vr[i] = vrow(vc, __builtin_amdgcn_readlane(ri, 8 * i));
+			gk[i] = vr[i].p0[kk];
+			g1[i] = vr[i].p1[kk];
+		}
+#pragma unroll
+		for (int i = 0; i < 8; ++i) {
+			pin(gk[i]);
+			pin(g1[i]);
+		}
+#pragma unroll
+		for (int i = 0; i < 8; ++i)
+			gk[i] = vval(vr[i], gk[i], g1[i]);
+	} else {
+#pragma unroll
+		for (int i = 0; i < 8; ++i)
+			gk[i] = l.G[__builtin_amdgcn_readlane(ri, 8 * i) * ld + kk];
+	}
 #pragma unroll
 	for (int i = 0; i < 8; ++i)
 		pin(gk[i]);
@@ -1989,6 +2136,97 @@ __device__ __forceinline__ int lds_fullpivlu(ldsd *M, int r, int c, ldsi *cperm)
 	return __popcll(__ballot(sig));
 }
 
+// The same factorization with the matrix in registers: one column per lane (c <= 64), its r <= R entries in
+// col[0..R).  Columns are not moved; each lane tracks the POSITION of its column (pos), which is what Eigen's
+// physical swaps change, and rows are swapped in the registers of every lane.  Same pivot rule (largest
+// |coefficient| of the corner, ties: lowest position, then lowest row), same arithmetic per entry (true
+// division for the multipliers, one FMA per update) as lds_fullpivlu; ~4 x fewer cycles per step, because the
+// pivot search is R compares per lane and one wave maximum instead of passes over LDS.  On return M holds U
+// in position order as lds_fullpivlu leaves it (the strictly lower part is NOT written: nobody reads L).
+template <int R>
+__device__ __forceinline__ int reg_fullpivlu(ldsd *M, int r, int c, ldsi *cperm)
+{
+	const int lane = lane_id();
+	const bool isc = lane < c;
+	double col[R];
+	{
+		const ldsd *src = M + (isc ? lane : 0);
+#pragma unroll
+		for (int i = 0; i < R; ++i)
+			col[i] = src[(i < r ? i : 0) * c];
+#pragma unroll
+		for (int i = 0; i < R; ++i)
+			col[i] = (isc && i < r) ? col[i] : 0.0;
+	}
+	int pos = lane;
+	const int size = min(r, c);
+	double maxpivot = 0.0;
+	int nonzero = size;
+#pragma unroll
+	for (int k = 0; k < R; ++k) {
+		if (k < size && nonzero == size) {  // (wave-uniform)
+			double best = -1.0;
+			int bi = k;
+#pragma unroll
+			for (int i = k; i < R; ++i) {
+				const double av = fabs(col[i]);
+				const bool take = i < r && av > best;
+				best = take ? av : best;
+				bi = take ? i : bi;
+			}
+			const bool cand = isc && pos >= k;
+			const double mx = wave_max(cand ? best : -1.0);
+			if (!(mx > 0.0)) {
+				nonzero = k;
+			} else {
+				// among the columns holding the maximum: the lowest position
+				const unsigned long long tie = __ballot(cand && best == mx);
+				int pl = __ffsll((long long)tie) - 1;
+				if (__popcll(tie) > 1) {
+					const int pmin = (int)wave_min((cand && best == mx) ? (double)pos : 1e18);
+					pl = __ffsll((long long)__ballot(cand && best == mx && pos == pmin)) - 1;
+				}
+				pl = uni(pl);
+				const int prow = __builtin_amdgcn_readlane(bi, pl);
+				const int oldpos = __builtin_amdgcn_readlane(pos, pl);
+				maxpivot = fmax(maxpivot, mx);
+				// row swap k <-> prow (every lane), column swap k <-> oldpos (positions only)
+#pragma unroll
+				for (int i = k + 1; i < R; ++i) {
+					const bool sw = i == prow;
+					const double t = col[i];
+					col[i] = sw ? col[k] : col[i];
+					col[k] = sw ? t : col[k];
+				}
+				pos = (pos == k) ? oldpos : ((lane == pl) ? k : pos);
+				const double piv = readlane_d(col[k], pl);
+#pragma unroll
+				for (int i = k + 1; i < R; ++i) {
+					const double li = readlane_d(col[i] / piv, pl);
+					col[i] = (pos > k && i < r) ? fma(-li, col[k], col[i]) : col[i];
+				}
+			}
+		}
+	}
+	// U in position order (rows i <= position), the column permutation, the rank
+	wave_sync();
+	if (isc) {
+		cperm[pos] = lane;
+#pragma unroll
+		for (int i = 0; i < R; ++i)
+			if (i < r && i <= pos)
+				M[i * c + pos] = col[i];
+	}
+	double ukk = 0.0;
+#pragma unroll
+	for (int i = 0; i < R; ++i)
+		ukk = (pos == i) ? col[i] : ukk;
+	const double thr = maxpivot * (kEpsMach * (double)size);
+	const bool sig = isc && pos < nonzero && fabs(ukk) > thr;
+	wave_sync();
+	return __popcll(__ballot(sig));
+}
+
 // K (c x dk, stride dk, dk = c - rank) = FullPivLU::kernel() from the factors above:
 // rows of the pivot columns = -U11^-1 U12, rows of the free columns = identity.
 __device__ __forceinline__ void lds_lu_kernel(const ldsd *M, int c, int rank, const ldsi *cperm, ldsd *K)
@@ -2044,6 +2282,61 @@ __device__ __forceinline__ void lds_lu_kernel(const ldsd *M, int c, int rank, co
 		for (int t = 0; t < PASS; ++t)
 			if (dst[t] >= 0)
 				K[dst[t]] = val[t];
+	}
+	wave_sync();
+}
+
+// Z (n x nzr, stride nzr) <- Z K in place (n x dk, stride dk), K = FullPivLU::kernel() of the factors in LU
+// (r x nzr, stride nzr; rank pivots): rows of the pivot columns = -U11^-1 U12, rows of the free columns = identity.
+// X = U11^-1 U12 overwrites U12; K itself is never formed: Z K is summed over t = 0 .. nzr-1 in natural order
+// with K[t][q] looked up through the inverse column permutation -- the same terms in the same order as the
+// explicit product.  One row of Z per lane (n <= 64), the row's dk <= MAXQ results in registers until every
+// lane has read its row.  ipos: scratch for nzr ints.
+template <int MAXQ>
+__device__ __forceinline__ void lds_basis_update(ldsd *Z, int n, int nzr, int rank, const ldsi *cperm, ldsd *LU, ldsi *ipos)
+{
+	const int lane = lane_id();
+	const int dk = nzr - rank;
+	if (lane < nzr)
+		ipos[cperm[lane]] = lane;
+	if (lane < dk) {
+		for (int i = rank - 1; i >= 0; --i) {
+			double sacc = LU[i * nzr + rank + lane];
+			for (int j = i + 1; j < rank; ++j)
+				sacc = fma(-LU[i * nzr + j], LU[j * nzr + rank + lane], sacc);
+			LU[i * nzr + rank + lane] = sacc / LU[i * nzr + i];
+		}
+	}
+	wave_sync();
+	double out[MAXQ];
+#pragma unroll
+	for (int q = 0; q < MAXQ; ++q)
+		out[q] = 0.0;
+	const ldsd *zrow = Z + (lane < n ? lane : 0) * nzr;
+	for (int t = 0; t < nzr; ++t) {
+		const double zt = zrow[t];
+		const int pt = uni(ipos[t]);
+		if (pt < rank) {
+			const ldsd *xr = LU + pt * nzr + rank;
+			double kq[MAXQ];
+#pragma unroll
+			for (int q = 0; q < MAXQ; ++q)
+				kq[q] = xr[q < dk ? q : 0];
+#pragma unroll
+			for (int q = 0; q < MAXQ; ++q)
+				out[q] = fma(zt, 0.0 - kq[q], out[q]);
+		} else {
+#pragma unroll
+			for (int q = 0; q < MAXQ; ++q)
+				out[q] = fma(zt, (pt - rank == q) ? 1.0 : 0.0, out[q]);
+		}
+	}
+	wave_sync();  // every lane has read its row
+	if (lane < n) {
+#pragma unroll
+		for (int q = 0; q < MAXQ; ++q)
+			if (q < dk)
+				Z[lane * dk + q] = out[q];
 	}
 	wave_sync();
 }
@@ -2181,7 +2474,7 @@ __device__ __forceinline__ void lds_reg_solve(const ldsd *M, const ldsd *r, int 
 }
 
 // Returns true (and replaces l.x by the reference's x_k) if levels 0..k could be replayed.
-template <bool WBC>
+template <bool WBC, int MAXQ = NR>
 __device__ __forceinline__ bool ref_replay(const SolveArgs &a, const Lds &l, int inst, int k, int n, int nz_entry,
 					   const WbcCtx &wx, const int (&jc)[NR / 4], double *res2_out)
 {
@@ -2224,7 +2517,7 @@ __device__ __forceinline__ bool ref_replay(const SolveArgs &a, const Lds &l, int
 	wave_sync();
 	const ldsd *Zr = ZB;
 	bool zident = true;  // Zr is the identity so far (no null tests on LDS pointers: offset 0 is a valid address)
-	int nzr = n, zoff = 0;
+	int nzr = n;
 	for (int j = 0; j <= k; ++j) {
 		int mj, pj;
 		if (WBC) {
@@ -2242,9 +2535,10 @@ __device__ __forceinline__ bool ref_replay(const SolveArgs &a, const Lds &l, int
 			return false;  // the LU's rank decisions differ from the QR's: leave the fast answer
 		const int cmin = min(mj, nzr);
 		RDBG("[replay]  level %d m %d nzr %d\n", j, mj, nzr);
-		// MK: M (mj x nzr) and, for j < k, the kernel matrix (nzr x (nzr - rank), rank = mj unless deficient;
-		// from the identity the kernel matrix IS the new basis and is built in ZB directly)
-		if (mj * nzr + (j < k ? (zident ? 0 : nzr * (nzr - cmin)) : cmin * cmin) > tvcap || cmin > kRegC || mj + nzr > kWave)
+		// MK: M (mj x nzr; for j < k its LU factors, then U11^-1 U12 inside them) and, at j == k, the m x m factor of
+		// lds_reg_solve.  The bases live in ZB: from the identity the kernel matrix IS the new basis, afterwards
+		// the basis is updated in place (lds_basis_update).
+		if (mj * nzr + (j < k ? 0 : cmin * cmin) > tvcap || cmin > kRegC || mj + nzr > kWave || nzr - cmin > MAXQ)
 			return false;
 		{
 			// M = A_j Zr -> TV (stride nzr),  r = b_j - A_j xr -> l.rhs
@@ -2252,14 +2546,15 @@ __device__ __forceinline__ bool ref_replay(const SolveArgs &a, const Lds &l, int
 			load_bm_from(bm, n, nzr, nzr, Zr, xr, zident);
 			const ProjDst dst = {MK, nzr, l.rhs};
 			if (WBC) {
+				// levels 2 and 3: the row sources of the fast path (rows of J_foot / J_b, zero beyond column 17)
 				if (j == 0) {
 					WbcEntrySrc<0> src(wx, a.wprm, l, jc);
 					project_task_mfma(src, mj, nzr, bm, dst, l);
 				} else if (j == 2) {
-					WbcEntrySrc<2> src(wx, a.wprm, l, jc);
+					WbcLevelSrc<2> src(wx, l);
 					project_task_mfma(src, mj, nzr, bm, dst, l);
 				} else if (j == 3) {
-					WbcEntrySrc<3> src(wx, a.wprm, l, jc);
+					WbcLevelSrc<3> src(wx, l);
 					project_task_mfma(src, mj, nzr, bm, dst, l);
 				} else {
 					WbcEntrySrc<4> src(wx, a.wprm, l, jc);
@@ -2307,7 +2602,11 @@ __device__ __forceinline__ bool ref_replay(const SolveArgs &a, const Lds &l, int
 		RSTAMP(35);
 		}
 		if (j < k) {
-			const int rank = uni(lds_fullpivlu(MK, mj, nzr, l.colpos));
+			// (blocks of up to 12 rows -- every level of the WBC hierarchy a later level can replay through
+			// except a tracking level with swing legs -- are factored in registers)
+			const int rank = uni(mj <= 6 ? reg_fullpivlu<6>(MK, mj, nzr, l.colpos)
+						      : (mj <= 12 ? reg_fullpivlu<12>(MK, mj, nzr, l.colpos)
+								  : lds_fullpivlu(MK, mj, nzr, l.colpos)));
 			RSTAMP(36);
 			const int dk = nzr - rank;
 			RDBG("[replay]  level %d rank %d\n", j, rank);
@@ -2315,44 +2614,19 @@ __device__ __forceinline__ bool ref_replay(const SolveArgs &a, const Lds &l, int
 				nzr = 0;
 				continue;
 			}
-			const int newoff = (zident || zoff != 0) ? 0 : n * nzr;
-			if (newoff + n * dk > Gcap || (!zident && newoff == 0 && n * dk > zoff))
+			if (n * dk > Gcap || dk > MAXQ)
 				return false;
-			ldsd *Zn = ZB + newoff;
-			if (!zident && mj * nzr + nzr * dk > tvcap)
-				return false;
-			ldsd *K = zident ? Zn : MK + mj * nzr;  // from the identity: Zn = I K (nzr == n)
-			lds_lu_kernel(MK, nzr, rank, l.colpos, K);
-			RSTAMP(37);
-			// Zn (n x dk) = Zr K: one output entry per lane and pass, the dot product in blocks of
-			// eight terms whose loads are in flight together (same summation order as a plain loop)
-			for (int e0 = 0; e0 < (zident ? 0 : n * dk); e0 += kWave) {
-				const int e = e0 + lane;
-				const bool on = e < n * dk;
-				const int row = on ? e / dk : 0, q = on ? e - (e / dk) * dk : 0;
-				double sacc = 0.0;
-				{
-					for (int t0 = 0; t0 < nzr; t0 += 8) {
-						double za[8], kb[8];
-#pragma unroll
-						for (int u = 0; u < 8; ++u) {
-							const int t = (t0 + u < nzr) ? t0 + u : 0;
-							za[u] = Zr[row * nzr + t];
-							kb[u] = K[t * dk + q];
-						}
-#pragma unroll
-						for (int u = 0; u < 8; ++u)
-							sacc = (t0 + u < nzr) ? fma(za[u], kb[u], sacc) : sacc;
-					}
-				}
-				if (on)
-					Zn[e] = sacc;
+			if (zident) {
+				lds_lu_kernel(MK, nzr, rank, l.colpos, ZB);  // Zn = I K (nzr == n)
+				RSTAMP(37);
+			} else {
+				RSTAMP(37);
+				lds_basis_update<MAXQ>(ZB, n, nzr, rank, l.colpos, MK, l.pivlane);
 			}
 			wave_sync();
 			RSTAMP(38);
-			Zr = Zn;
+			Zr = ZB;
 			zident = false;
-			zoff = newoff;
 			nzr = dk;
 		}
 	}
@@ -2396,6 +2670,8 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l_in,
 		l.ldv = (KC == 0) ? LDV : kCLdv;
 		l.xrows = kCXrows;
 	}
+	// the virtual rows of level 1 (compact layout; unused otherwise)
+	const VRowCtx vc = {l.G, l.Z, ld, wx.clp, wx.nc, a.wprm.friction_quirk, a.wprm.mu};
 	const int nz = uni(st.nz), P = HARD ? uni(st.P) : 0;
 	const int nstore = a.n;
 	if (WBC && KC >= 0) {
@@ -2468,7 +2744,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l_in,
 			if (k == 1) {
 				if (p > 0 && doD) {
 					load_bm(bm, n, nz, ld, l);
-					wbc_project_level1(wx, a.wprm, jc, nz, ld, bm, dstG, l);
+					wbc_project_level1<COMPACT>(wx, a.wprm, jc, nz, ld, bm, dstG, l);
 				}
 			} else if (m > 0 && doA) {
 				load_bm<kWbcKB>(bm, n, nz, ld, l);
@@ -2941,13 +3217,13 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l_in,
 			double pi = 0.0;
 			if (!(prev_full && vmask == prev_vmask)) {
 				wave_sync();
-				if (!HARD && mB == 0 && nV >= 1 && nV <= 8 && nV <= nz && eqp_dual8(l, nz, nV, ld, &pi)) {
+				if (!HARD && mB == 0 && nV >= 1 && nV <= 8 && nV <= nz && eqp_dual8<COMPACT>(l, nz, nV, ld, &pi, vc)) {
 #ifdef HOQP_PROFILE
 					if (a.dbg && lane == 0)
 						a.dbg[(size_t)blockIdx.x * kDbgSlots + 50] += 1;  // steps through the small side
 #endif
 				} else
-				pi = eqp_step<HARD, (WBC && GATE && !HARD && KC >= 0)>(a, l, st, ld, nz, rank, mB, w, nV, &k1, &overflow);
+				pi = eqp_step<HARD, COMPACT, COMPACT>(a, l, st, ld, nz, rank, mB, w, nV, &k1, &overflow, vc);
 				if (overflow) {
 					st.status |= HOQP_STATUS_WORKSPACE;
 					break;
@@ -3007,7 +3283,9 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l_in,
 			wave_sync();
 			l.tmp[lane] = (lane < nz) ? pi : 0.0;
 			wave_sync();
-			if (WBC && KC >= 0)
+			if (COMPACT)
+				rows_dot_v<3>(vc, Pn, nz, l.tmp, l.c);  // at most 40 rows, 12 of them stored
+			else if (WBC && KC >= 0)
 				rows_dot<3>(l.G, Pn, ld, nz, l.tmp, l.c);  // at most 40 rows
 			else
 				rows_dot<4>(l.G, Pn, ld, nz, l.tmp, l.c);
@@ -3173,7 +3451,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l_in,
 			     0)) {
 		wave_sync();
 		double res2 = 0.0;
-		if (ref_replay<WBC>(a, l, inst, k, n, nz, wx, jc, &res2))
+		if (ref_replay<WBC, (COMPACT ? 24 : NR)>(a, l, inst, k, n, nz, wx, jc, &res2))
 			level_res2 = res2 + res_const;
 	}
 #endif
