@@ -217,14 +217,36 @@ public:
 	HoQpProblem(TaskDefinition &new_task, std::shared_ptr<HoQpProblem> higher_pri_problem)
 		: curr_task_(new_task), higher_pri_problem_(higher_pri_problem)
 	{
+		// The solve itself is lazy (below), but malformed input fails HERE, where the reference's constructor
+		// would have failed (dimension asserts of math.hpp:31, 48 and ho_qp_problem.cpp:108-114), not at some
+		// later getter on another thread.
+		const TaskDefinition &t = curr_task_;
+		if (t.A.rows() != t.b.rows() || t.D.rows() != t.f.rows())
+			throw std::invalid_argument("HoQpProblem: A/b or D/f row counts differ");
+		if (t.A.rows() > HOQP_MAX_EQ_ROWS || t.D.rows() > HOQP_MAX_INEQ_ROWS)
+			throw std::invalid_argument("HoQpProblem: more rows than HOQP_MAX_EQ_ROWS / HOQP_MAX_INEQ_ROWS");
+		if (t.A.rows() > 0 && t.D.rows() > 0 && t.A.cols() != t.D.cols())
+			throw std::invalid_argument("HoQpProblem: A and D have different column counts");
+		const int n = (int)std::max(t.A.cols(), t.D.cols());
+		if (n > HOQP_MAX_VARS)
+			throw std::invalid_argument("HoQpProblem: more than HOQP_MAX_VARS decision variables");
 		if (higher_pri_problem_)
 			chain_ = higher_pri_problem_->chain_;
+		int P = (int)t.D.rows();
+		for (auto &c : chain_) {
+			const int nc = (int)std::max(c.A.cols(), c.D.cols());
+			if (n > 0 && nc > 0 && nc != n)
+				throw std::invalid_argument("HoQpProblem: column count differs from the higher-priority problem's");
+			P += (int)c.D.rows();
+		}
+		if (P > HOQP_MAX_INEQ_ROWS)
+			throw std::invalid_argument("HoQpProblem: more than HOQP_MAX_INEQ_ROWS inequality rows in the chain");
 		chain_.push_back(curr_task_);
 		if ((int)chain_.size() > HOQP_MAX_LEVELS)
-			throw std::runtime_error("HoQpProblem: more than HOQP_MAX_LEVELS levels");
+			throw std::invalid_argument("HoQpProblem: more than HOQP_MAX_LEVELS levels");
 	}
 
-	TaskDefinition GetStackedTasks()
+	TaskDefinition GetStackedTasks() const
 	{
 		// StackTasks: ConcatenateTasks(curr, prev) -- newest first (ho_qp_problem.cpp:83-86)
 		TaskDefinition st = chain_.back();
@@ -232,21 +254,22 @@ public:
 			st = ConcatenateTasks(st, chain_[k]);
 		return st;
 	}
-	hoqp::MatrixXd GetStackedNullspaceMatrix() { return Solved().stacked_Z_; }
-	int GetStackedNumSlackVars()
+	hoqp::MatrixXd GetStackedNullspaceMatrix() const { return Solved().stacked_Z_; }
+	int GetStackedNumSlackVars() const
 	{
 		int P = 0;  // known without solving
 		for (auto &t : chain_)
 			P += (int)t.D.rows();
 		return P;
 	}
-	hoqp::VectorXd GetSolution() { return Solved().x_; }
-	hoqp::VectorXd GetSlackSolutions() { return Solved().slack_; }
-	hoqp::VectorXd GetStackedSlackSolutions() { return Solved().stacked_slack_; }
-	int GetStatus() { return Solved().status_; }
+	hoqp::VectorXd GetSolution() const { return Solved().x_; }
+	hoqp::VectorXd GetSlackSolutions() const { return Solved().slack_; }
+	hoqp::VectorXd GetStackedSlackSolutions() const { return Solved().stacked_slack_; }
+	int GetStatus() const { return Solved().status_; }
 
 private:
-	HoQpProblem &Solved()
+	// (the results are a cache of a pure function of the chain: mutable, so that the getters stay const)
+	const HoQpProblem &Solved() const
 	{
 		if (!solved_) {
 			Solve();
@@ -255,7 +278,7 @@ private:
 		return *this;
 	}
 
-	void Solve()
+	void Solve() const
 	{
 		auto hd = hoqp::thread_handle();
 		const int L = (int)chain_.size();
@@ -322,11 +345,11 @@ private:
 	TaskDefinition curr_task_;
 	std::shared_ptr<HoQpProblem> higher_pri_problem_;
 	std::vector<TaskDefinition> chain_;
-	hoqp::VectorXd x_, slack_, stacked_slack_;
-	hoqp::MatrixXd stacked_Z_;
-	int num_stacked_slack_ = 0;
-	int status_ = 0;
-	bool solved_ = false;
+	mutable hoqp::VectorXd x_, slack_, stacked_slack_;
+	mutable hoqp::MatrixXd stacked_Z_;
+	mutable int num_stacked_slack_ = 0;
+	mutable int status_ = 0;
+	mutable bool solved_ = false;
 };
 
 // ---------------------------------------------------------------------------

@@ -1,4 +1,10 @@
-"""Synthetic "ANYmal-C-like" quadruped: batched dynamics terms for the HO-QP solve.
+"""TEST INFRASTRUCTURE (with the rest of oracle/): the numpy "ANYmal-C-like" quadruped model.
+
+It is the CHECKER of the device dynamics-terms producer (hoqp_wbc_dynamics_batched) and the input
+generator of the tests; the product package only keeps the state / command samplers
+(quadruped_locomotion_amd/state_sampler.py), which are re-exported here.
+
+Synthetic "ANYmal-C-like" quadruped: batched dynamics terms for the HO-QP solve.
 
 The reference pulls M, h, J_c, J_c_dot*u, J_b and foot positions from a Drake
 MultibodyPlant built from Drake's ANYmal-C URDF (``src/dynamics/dynamics.cpp:25-29,
@@ -27,6 +33,8 @@ from __future__ import annotations
 
 import numpy as np
 
+from quadruped_locomotion_amd.state_sampler import INITIAL_JOINT_CONFIG, sample_states, standing_state  # noqa: F401
+
 NU = 18
 NJ = 12
 GRAV = 9.81
@@ -48,10 +56,6 @@ HIP_COM = np.array([0.0, 0.04, 0.0])
 THIGH_COM = np.array([0.0, 0.02, -0.12])
 SHANK_COM = np.array([0.0, 0.0, -0.14])
 
-# kInitialJointConfig, anymal_constants.hpp:48-52
-INITIAL_JOINT_CONFIG = np.array(
-    [0, 0, 0, 0, 0.5, 0.5, -0.5, -0.5, -0.9, -0.9, 0.9, 0.9], dtype=np.float64
-)
 
 
 def _quat_to_rot(qw):
@@ -222,58 +226,6 @@ def dynamics_terms(q, u, include_gravity=True):
 
 def total_mass():
     return BASE_MASS + 4 * (HIP_MASS + THIGH_MASS + SHANK_MASS)
-
-
-# ---------------------------------------------------------------------------
-# state / command samplers for the BASELINE configs
-# ---------------------------------------------------------------------------
-
-def _euler_to_quat(roll, pitch, yaw):
-    cr, sr = np.cos(roll / 2), np.sin(roll / 2)
-    cp, sp = np.cos(pitch / 2), np.sin(pitch / 2)
-    cy, sy = np.cos(yaw / 2), np.sin(yaw / 2)
-    return np.stack(
-        [cr * cp * cy + sr * sp * sy, sr * cp * cy - cr * sp * sy,
-         cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy], axis=-1)
-
-
-def standing_state():
-    """C1: identity orientation, height 0.5, kInitialJointConfig, u = 0, zero commands, mask 1111."""
-    q = np.zeros((1, 19))
-    q[0, 0] = 1.0
-    q[0, 6] = 0.5
-    q[0, 7:] = INITIAL_JOINT_CONFIG
-    u = np.zeros((1, 18))
-    return dict(q=q, u=u, base_cmd=np.zeros((1, 9)), leg_cmd=np.zeros((1, 36)),
-                contact=np.ones((1, 4), dtype=np.int32))
-
-
-def sample_states(n, seed, contact="stance"):
-    """Randomised states: C2 'stance' (mask 1111), C3 'trot' (25% LF+RH, 25% RF+LH, 50% all),
-    C5 'three' (one leg swinging, uniform)."""
-    rng = np.random.default_rng(seed)
-    q = np.zeros((n, 19))
-    q[:, 0:4] = _euler_to_quat(rng.uniform(-0.2, 0.2, n), rng.uniform(-0.2, 0.2, n),
-                               rng.uniform(-np.pi, np.pi, n))
-    q[:, 4:6] = 0.0
-    q[:, 6] = rng.uniform(0.4, 0.6, n)
-    q[:, 7:] = INITIAL_JOINT_CONFIG + rng.uniform(-0.3, 0.3, (n, 12))
-    u = rng.normal(0.0, 0.3, (n, 18))
-    base_cmd = rng.normal(0.0, 0.5, (n, 9))
-    contact_arr = np.ones((n, 4), dtype=np.int32)
-    if contact == "trot":
-        r = rng.uniform(size=n)
-        contact_arr[r < 0.25] = np.array([1, 0, 0, 1], dtype=np.int32)
-        contact_arr[(r >= 0.25) & (r < 0.5)] = np.array([0, 1, 1, 0], dtype=np.int32)
-    elif contact == "three":
-        sw = rng.integers(0, 4, n)
-        contact_arr[np.arange(n), sw] = 0
-    elif contact != "stance":
-        raise ValueError(contact)
-    leg_cmd = np.zeros((n, 36))
-    leg_cmd[:, 0:12] = rng.uniform(-0.05, 0.05, (n, 12))  # offset from current foot pos, fixed up below
-    leg_cmd[:, 12:36] = rng.normal(0.0, 0.5, (n, 24))
-    return dict(q=q, u=u, base_cmd=base_cmd, leg_cmd=leg_cmd, contact=contact_arr)
 
 
 def make_wbc_inputs(state, include_gravity=True):

@@ -169,7 +169,7 @@ def solve_tasks(tasks, n, cfg=None):
 
 
 def pack_states(inp) -> "C.Array":
-    """dict of batched arrays (anymal_model.make_wbc_inputs) -> array of WbcState."""
+    """dict of batched arrays (oracle/anymal_model.make_wbc_inputs) -> array of WbcState."""
     N = inp["M"].shape[0]
     arr = (WbcState * N)()
     raw = np.frombuffer(arr, dtype=np.uint8).reshape(N, C.sizeof(WbcState))

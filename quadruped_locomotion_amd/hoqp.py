@@ -327,7 +327,7 @@ class HoQpSolver:
                     x_levels=t.zeros(batch, 5, 30, dtype=t.float64, device=dev))
 
     def to_device(self, inp):
-        """dict of numpy arrays (anymal_model.make_wbc_inputs) -> dict of device tensors."""
+        """dict of numpy arrays (the layout of hoqp_wbc_inputs) -> dict of device tensors."""
         t = self.torch
         return {k: t.as_tensor(v).contiguous().to(self.device) for k, v in inp.items()}
 

@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from oracle import oracle as orc  # noqa: E402
-from quadruped_locomotion_amd import anymal_model as am  # noqa: E402
+from oracle import anymal_model as am  # noqa: E402
 import proto_levelsolver as pl  # noqa: E402
 
 CASES = [

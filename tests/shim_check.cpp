@@ -55,6 +55,43 @@ int main(int argc, char **argv)
 {
 	if (argc < 2)
 		return 2;
+	if (std::string(argv[1]) == "--validate") {
+		// constructor-time validation of include/hoqp.hpp (no GPU needed: nothing is solved)
+		int caught = 0;
+		auto expect_throw = [&](TaskDefinition t, std::shared_ptr<control::HoQpProblem> prev) {
+			try {
+				control::HoQpProblem p(t, prev);
+			} catch (const std::invalid_argument &) {
+				++caught;
+			}
+		};
+		TaskDefinition ok;
+		ok.A = MatrixXd::Identity(3, 8);
+		ok.b = VectorXd::Zero(3);
+		std::shared_ptr<control::HoQpProblem> first(new control::HoQpProblem(ok));
+		TaskDefinition t1 = ok;
+		t1.b = VectorXd::Zero(2);  // A / b rows differ
+		expect_throw(t1, nullptr);
+		TaskDefinition t2;
+		t2.D = MatrixXd::Identity(4, 8);
+		t2.f = VectorXd::Zero(5);  // D / f rows differ
+		expect_throw(t2, nullptr);
+		TaskDefinition t3;
+		t3.A = MatrixXd::Identity(3, HOQP_MAX_VARS + 1);  // too many variables
+		t3.b = VectorXd::Zero(3);
+		expect_throw(t3, nullptr);
+		TaskDefinition t4;
+		t4.A = MatrixXd::Identity(3, 9);  // column count differs from the parent's
+		t4.b = VectorXd::Zero(3);
+		expect_throw(t4, first);
+		TaskDefinition t5;
+		t5.D = MatrixXd::Identity(HOQP_MAX_INEQ_ROWS + 1, 8);  // too many inequality rows
+		t5.f = VectorXd::Zero(HOQP_MAX_INEQ_ROWS + 1);
+		expect_throw(t5, nullptr);
+		const control::HoQpProblem &cref = *first;  // getters are const
+		std::printf("validate caught %d of 5, stacked slack vars %d\n", caught, cref.GetStackedNumSlackVars());
+		return caught == 5 ? 0 : 1;
+	}
 	std::ifstream in(argv[1]);
 	std::string kind;
 	int semantics;

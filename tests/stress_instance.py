@@ -3,7 +3,7 @@
 import sys, os
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from quadruped_locomotion_amd import anymal_model as am, hoqp
+from oracle import anymal_model as am, hoqp
 from oracle import oracle
 mode, kind, seed, N, i = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
 np.set_printoptions(linewidth=220, precision=4)

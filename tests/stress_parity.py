@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from quadruped_locomotion_amd import anymal_model as am  # noqa: E402
+from oracle import anymal_model as am  # noqa: E402
 from quadruped_locomotion_amd import hoqp  # noqa: E402
 from oracle import oracle  # noqa: E402
 

@@ -8,7 +8,7 @@ basis-invariant quantities are compared (final x, slacks, per-level residual nor
 import numpy as np
 import pytest
 
-from quadruped_locomotion_amd import anymal_model as am
+from oracle import anymal_model as am
 
 pytestmark = pytest.mark.gpu
 

@@ -6,7 +6,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from quadruped_locomotion_amd import anymal_model as am
+from oracle import anymal_model as am
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))

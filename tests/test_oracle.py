@@ -10,7 +10,7 @@ import scipy.linalg as sla
 import scipy.optimize as sopt
 
 import proto_levelsolver as pl
-from quadruped_locomotion_amd import anymal_model as am
+from oracle import anymal_model as am
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -354,3 +354,17 @@ def test_base_walk_plan_is_the_straight_line():
     ax0, ay0 = p0 + 2 * d
     assert np.allclose(ref[:2], [ax0 + ay0 * 0.125, d[0] + d[1] * 0.125], atol=1e-12)
     assert np.allclose(bp.base_walk_eval(alpha, 25.0, 0.45, fix_layout=True)[:2], p0 + 25.0 * d, atol=1e-12)  # last segment extrapolates
+
+
+def test_oracle_under_sanitizers():
+    """SURVEY.md section 5 (host tests under ASan / UBSan): every entry point of the restatement on edge shapes,
+    built with -fsanitize=address,undefined (oracle/Makefile: asan_check) -- the sanitizers abort on a finding."""
+    import os
+    import subprocess
+
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    subprocess.check_call(["make", "-s", "-C", root, "asan_check"])
+    res = subprocess.run([os.path.join(root, "asan_check")], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert "asan_check: ok" in res.stdout

@@ -24,7 +24,7 @@ def _worker(rank, world, port, total, tmp):
     import torch.distributed as dist
 
     from oracle import oracle as orc
-    from quadruped_locomotion_amd import anymal_model as am
+    from oracle import anymal_model as am
     from quadruped_locomotion_amd import parallel
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -84,7 +84,7 @@ def test_shard_bounds():
 def test_two_rank_gather_and_stats(tmp_path, total):
     sys.path.insert(0, ROOT)
     from oracle import oracle as orc
-    from quadruped_locomotion_amd import anymal_model as am
+    from oracle import anymal_model as am
 
     orc.build()
     port = _free_port()

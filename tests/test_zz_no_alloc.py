@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from quadruped_locomotion_amd import anymal_model as am
+from oracle import anymal_model as am
 from quadruped_locomotion_amd import hoqp
 
 pytestmark = pytest.mark.gpu

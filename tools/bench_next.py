@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from quadruped_locomotion_amd import anymal_model as am  # noqa: E402
+from oracle import anymal_model as am  # noqa: E402
 from quadruped_locomotion_amd import hoqp  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
-from quadruped_locomotion_amd import anymal_model as am  # noqa: E402
+from oracle import anymal_model as am  # noqa: E402
 from quadruped_locomotion_amd import hoqp  # noqa: E402
 
 

@@ -15,7 +15,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from quadruped_locomotion_amd import anymal_model as am  # noqa: E402
+from oracle import anymal_model as am  # noqa: E402
 
 
 def fmt(a):
