@@ -509,6 +509,7 @@ static int launch_solve(hoqp_handle *h, SolveArgs &a, hipStream_t s, bool wbc, b
 				sum[16] / batch, sum[17] / batch, sum[18] / batch, sum[19] / batch, sum[20] / batch,
 				sum[21] / batch, sum[22] / batch);
 			fprintf(stderr, "[hoqp profile] update parts: rows=%.0f of which issue=%.0f wait=%.0f dots=%.0f stores=%.0f\n", sum[27] / batch, sum[28] / batch, sum[29] / batch, sum[30] / batch, sum[31] / batch);
+			fprintf(stderr, "[hoqp profile] QP steps through the 16 x 16 matrix-core dual system: %.3f per instance\n", sum[55] / batch);
 			fprintf(stderr, "[hoqp profile] QP steps through the 8 x 8 dual system: %.3f per instance; factored steps: rows <= 8: %.3f, <= 16: %.3f "
 					"(of which full rank %.3f), mean rows %.2f\n",
 				sum[50] / batch, sum[54] / batch, sum[51] / batch, sum[52] / batch, sum[14] > 0 ? sum[53] / sum[14] : 0.0);

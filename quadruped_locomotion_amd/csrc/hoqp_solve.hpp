@@ -1942,6 +1942,190 @@ __device__ __forceinline__ bool eqp_dual8(const Lds &l, int nz, int nV, int ld, 
 	return true;
 }
 
+// ---------------------------------------------------------------------------
+// The same step for up to 16 rows, on the matrix cores (fused reference kernel, level 1: every row is a virtual
+// row).  Two things make the small side work where eqp_dual8 gives up:
+//  * Structural dependence is removed first.  The four pyramid rows of one contact, [+-1, 0, -mu] and
+//    [0, +-1, -mu] on three coordinates e = (a, b, c) of x, have orthogonal columns (B'B = diag(2, 2, 4 mu^2)); when
+//    all four are violated their least-squares term sum_i (s_i + B_i e)^2 is minimised by the UNIQUE e* =
+//    -(B'B)^-1 B's, so the four dependent rows are replaced by the three rows of Z that pick a, b, c, with targets
+//    e* = (-(s1 - s2) / 2, -(s3 - s4) / 2, (s1 + s2 + s3 + s4) / (4 mu)).  The compacted rows G~ span the same
+//    row space, and p = G~'(G~ G~')^-1 t is the minimum-norm minimiser of the same model -- what the
+//    factorization path computes with its rank-deficient least squares (67 % of the factored steps).
+//  * The Gram matrix is one 16 x 16 tile: six v_mfma_f64_16x16x4_f64 with the SAME register as both operands
+//    (A[i][k] and B[k][j] = G~[j][k] sit in the same lane), then a Gauss-Jordan on the tile's own register layout
+//    (K[i = lane / 16 + 4 r][j = lane % 16]): the pivot column comes by DPP row broadcast, the pivot row by one
+//    cross-row permute.  Rows are scaled to unit norm first, so the acceptance test (smallest pivot above 1e-4)
+//    measures conditioning, not the scale difference between torque rows and friction rows.
+// Returns false (caller factors as usual) for more than 16 compacted rows or an ill-conditioned set.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ VRow crow(const VRowCtx &v, int code)
+{
+	// code < 64: row `code` of the level's block; 64 + 3 c + j: row of Z that picks coordinate j of contact c
+	const int z = code >= 64 ? code - 64 : 0;
+	const int c = (z * 11) >> 5, j = z - 3 * c;
+	const int col = v.quirk ? kNB + wbc_pick(v.clp, c) * 3 : kNU + 3 * c;
+	VRow o = vrow(v, code < 64 ? code : 0);
+	if (code >= 64) {
+		o.p0 = v.Z + (col + j) * v.ld;
+		o.p1 = o.p0;
+		o.s0 = 1.0;
+		o.s1 = 0.0;
+	}
+	return o;
+}
+
+template <int K>
+__device__ __forceinline__ void gj16_steps(double (&M)[4], double (&gv)[4], int nR, double &minpiv)
+{
+	if constexpr (K < 16) {
+		if (K < nR) {
+			const int lane = lane_id(), j16 = lane & 15, q4 = lane >> 4;
+			constexpr int kr = K >> 2, kq = K & 3;
+			const double piv = readlane_d(M[kr], kq * 16 + K);
+			minpiv = fmin(minpiv, piv);
+			const double rpv = fast_rcp(piv);
+			const double rowk = __shfl(M[kr], kq * 16 + j16) * rpv;  // M[K][j] / piv
+			const double gk = readlane_d(gv[kr], kq * 16) * rpv;
+#pragma unroll
+			for (int r = 0; r < 4; ++r) {
+				const double cik = dpp_d<0x150 + K>(M[r]);  // row_newbcast: M[i][K], i = q4 + 4 r
+				const bool isk = (r == kr) && (q4 == kq);
+				M[r] = isk ? rowk : fma(-cik, rowk, M[r]);
+				gv[r] = isk ? gk : fma(-cik, gk, gv[r]);
+			}
+			gj16_steps<K + 1>(M, gv, nR, minpiv);
+		}
+	}
+}
+
+__device__ __forceinline__ bool eqp_dual16(const SolveArgs &a, LevelState &st, const Lds &l, const VRowCtx &vc, int nz,
+					   unsigned long long vmask, double si, double *p_out)
+{
+	(void)a;
+	(void)st;
+	HOQP_STAMP(13);
+	const int lane = lane_id(), j16 = lane & 15, q4 = lane >> 4;
+	// contacts whose four pyramid rows are all violated
+	unsigned long long vm1 = vmask;
+	int ng = 0;
+#pragma unroll
+	for (int c = 0; c < 4; ++c) {
+		const bool full = c < vc.nc && ((vmask >> (2 * kNJ + 4 * c)) & 0xFull) == 0xFull;
+		vm1 = full ? (vm1 & ~(0xFull << (2 * kNJ + 4 * c))) : vm1;
+		ng += full;
+	}
+	const int n1 = __popcll(vm1), nR = n1 + 3 * ng;
+	if (nR < 1 || nR > 16 || nR > nz)
+		return false;
+	wave_sync();
+	if ((vm1 >> lane) & 1ull) {
+		const int idx = __popcll(vm1 & ((1ull << lane) - 1ull));
+		l.vlist[idx] = lane;
+		l.rhs[idx] = 0.0 - si;
+	}
+	{
+		int g = 0;
+#pragma unroll
+		for (int c = 0; c < 4; ++c) {
+			const bool full = c < vc.nc && ((vmask >> (2 * kNJ + 4 * c)) & 0xFull) == 0xFull;
+			const int r0 = 2 * kNJ + 4 * c;
+			if (full) {
+				const double s1 = readlane_d(si, r0), s2 = readlane_d(si, r0 + 1), s3 = readlane_d(si, r0 + 2),
+					     s4 = readlane_d(si, r0 + 3);
+				if (lane < 3) {
+					const double t = (lane == 0) ? -0.5 * (s1 - s2)
+								     : ((lane == 1) ? -0.5 * (s3 - s4) : ((s1 + s2) + (s3 + s4)) / (4.0 * vc.mu));
+					l.vlist[n1 + 3 * g + lane] = 64 + 3 * c + lane;
+					l.rhs[n1 + 3 * g + lane] = t;
+				}
+				++g;
+			}
+		}
+	}
+	wave_sync();
+	HOQP_STAMP(8);
+	// operand: G~[i = j16][k = 4 kb + q4]
+	const bool rowon = j16 < nR;
+	const VRow vr = crow(vc, l.vlist[rowon ? j16 : 0]);
+	double a0[6], a1[6];
+#pragma unroll
+	for (int kb = 0; kb < 6; ++kb) {
+		const int k = 4 * kb + q4;
+		a0[kb] = vr.p0[k < nz ? k : 0];
+		a1[kb] = vr.p1[k < nz ? k : 0];
+	}
+	double t_i[4];
+#pragma unroll
+	for (int r = 0; r < 4; ++r)
+		t_i[r] = l.rhs[(q4 + 4 * r < nR) ? q4 + 4 * r : 0];
+#pragma unroll
+	for (int kb = 0; kb < 6; ++kb) {
+		pin(a0[kb]);
+		pin(a1[kb]);
+	}
+	d4v acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+	for (int kb = 0; kb < 6; ++kb) {
+		const double v = (rowon && 4 * kb + q4 < nz) ? vval(vr, a0[kb], a1[kb]) : 0.0;
+		acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
+	}
+	// Jacobi scaling: d_j = K[j][j] sits in lane (j & 3) * 16 + j, register j >> 2
+	double M[4], gv[4];
+	double dj = 0.0;
+#pragma unroll
+	for (int r = 0; r < 4; ++r) {
+		M[r] = acc[r];
+		dj = (q4 + 4 * r == j16) ? acc[r] : dj;  // my own diagonal entry, if I hold one
+	}
+	dj += __shfl_xor(dj, 16);
+	dj += __shfl_xor(dj, 32);  // every lane: d_(j16)
+	const bool colon = j16 < nR;
+	if (__ballot(colon && !(dj > 1e-290)) != 0ull)
+		return false;  // a zero row
+	const double rsj = colon ? fast_rsqrt(dj) : 1.0;
+#pragma unroll
+	for (int r = 0; r < 4; ++r) {
+		const int i = q4 + 4 * r;
+		const double rsi = __shfl(rsj, q4 * 16 + i);  // (lane q4 * 16 + i of my row holds column i's scale)
+		const bool on = i < nR && colon;
+		M[r] = on ? M[r] * rsi * rsj : ((i == j16) ? 1.0 : 0.0);
+		gv[r] = (i < nR) ? t_i[r] * rsi : 0.0;
+	}
+	double minpiv = 1e300;
+	HOQP_STAMP(9);
+	gj16_steps<0>(M, gv, nR, minpiv);
+	HOQP_STAMP(10);
+	if (!(minpiv > 1e-4))
+		return false;
+	// lambda_i = gv (scaled system) * rs_i;  p = G~' lambda.  The operand registers still hold G~[i = j16][k = 4 kb + q4]:
+	// scale each by lambda_(j16), sum over the 16 lanes of the row (DPP), and hand coordinate k = 4 kb + q4 to
+	// lane k -- no second trip through LDS.
+	double lamsrc = gv[0];
+#pragma unroll
+	for (int r = 1; r < 4; ++r)
+		lamsrc = ((j16 >> 2) == r) ? gv[r] : lamsrc;  // lane (i & 3) * 16 + i holds lambda~_i here
+	const double lam = rowon ? __shfl(lamsrc, (j16 & 3) * 16 + j16) * rsj : 0.0;
+	double red[6];
+#pragma unroll
+	for (int kb = 0; kb < 6; ++kb) {
+		double v = (rowon && 4 * kb + q4 < nz) ? vval(vr, a0[kb], a1[kb]) * lam : 0.0;
+		v += dpp_d<0xB1>(v);
+		v += dpp_d<0x4E>(v);
+		v += dpp_d<0x141>(v);
+		v += dpp_d<0x140>(v);
+		red[kb] = v;  // p_(4 kb + q4) in every lane of row q4
+	}
+	double psrc = red[0];
+#pragma unroll
+	for (int kb = 1; kb < 6; ++kb)
+		psrc = (j16 == kb) ? red[kb] : psrc;  // lane q4 * 16 + kb offers p_(4 kb + q4)
+	const double p = __shfl(psrc, (lane & 3) * 16 + ((lane >> 2) < 6 ? (lane >> 2) : 0));
+	*p_out = (lane < nz) ? p : 0.0;
+	HOQP_STAMP(11);
+	return true;
+}
+
 // Level update on the rows of Z and G (row r = c + 16*slot):  d_r = row_r . y  -> l.S[r], then
 // the rows lose their first `rank` coordinates (shifted store).  y is in l.tmp.
 template <int NS>
@@ -3217,13 +3401,25 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l_in,
 			double pi = 0.0;
 			if (!(prev_full && vmask == prev_vmask)) {
 				wave_sync();
-				if (!HARD && mB == 0 && nV >= 1 && nV <= 8 && nV <= nz && eqp_dual8<COMPACT>(l, nz, nV, ld, &pi, vc)) {
+				bool small = !HARD && mB == 0 && nV >= 1 && nV <= 8 && nV <= nz && eqp_dual8<COMPACT>(l, nz, nV, ld, &pi, vc);
 #ifdef HOQP_PROFILE
-					if (a.dbg && lane == 0)
-						a.dbg[(size_t)blockIdx.x * kDbgSlots + 50] += 1;  // steps through the small side
+				if (small && a.dbg && lane == 0)
+					a.dbg[(size_t)blockIdx.x * kDbgSlots + 50] += 1;  // steps through the small side
 #endif
-				} else
-				pi = eqp_step<HARD, COMPACT, COMPACT>(a, l, st, ld, nz, rank, mB, w, nV, &k1, &overflow, vc);
+				if (COMPACT && !small && mB == 0 && nV >= 1) {
+					small = eqp_dual16(a, st, l, vc, nz, vmask, si, &pi);
+#ifdef HOQP_PROFILE
+					if (small && a.dbg && lane == 0)
+						a.dbg[(size_t)blockIdx.x * kDbgSlots + 55] += 1;  // steps through the 16 x 16 tile
+#endif
+					// (eqp_dual16 used l.vlist for its compacted rows: restore the list of violated rows)
+					wave_sync();
+					if (viol)
+						l.vlist[__popcll(vmask & ((1ull << lane) - 1ull))] = lane;
+					wave_sync();
+				}
+				if (!small)
+					pi = eqp_step<HARD, COMPACT, COMPACT>(a, l, st, ld, nz, rank, mB, w, nV, &k1, &overflow, vc);
 				if (overflow) {
 					st.status |= HOQP_STATUS_WORKSPACE;
 					break;

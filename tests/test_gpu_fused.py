@@ -20,9 +20,10 @@ def _masked_inputs(n_per_mask, seed):
 
 @pytest.mark.parametrize("mode", ["reference", "paper"])
 def test_fused_equals_unfused(solver_factory, mode):
-    """Same operands, same arithmetic: x, slacks and level residuals of the fused kernel are
-    bit-identical to the three-kernel path; tau and the validity residuals (formed from M / J
-    directly in the fused tail) agree to rounding; flags and active rows identical outside the band."""
+    """Same operands: under paper semantics (same arithmetic in both) x, slacks and level residuals of the
+    fused kernel are bit-identical to the three-kernel path; under reference semantics to 1e-9 (the fused
+    kernel's level-1 QP goes through the matrix-core dual system); tau and the validity residuals (formed
+    from M / J directly in the fused tail) agree to rounding; flags and active rows identical outside the band."""
     s = solver_factory(mode)
     inp = _masked_inputs(24, 5)
     inp2 = am.make_wbc_inputs(am.sample_states(1024, 6, "trot"))
@@ -33,7 +34,15 @@ def test_fused_equals_unfused(solver_factory, mode):
         s.synchronize()
         assert np.all(a["status"] == 0) and np.all(b["status"] == 0)
         for key in ("x", "v", "level_res", "x_levels", "qdd"):
-            assert np.array_equal(a[key], b[key]), key
+            if mode == "paper":
+                assert np.array_equal(a[key], b[key]), key
+            else:
+                # reference semantics: the fused kernel takes the steps of the torque / friction level's QP
+                # through the 16 x 16 Gram system on the matrix cores (eqp_dual16), the generic kernel through
+                # the factorization: the same minimiser by different arithmetic, and everything after that
+                # level starts from an x_1 that differs in the last digits
+                err = np.abs(a[key] - b[key]) / np.maximum(1.0, np.abs(b[key]))
+                assert err.max() <= 1e-9, (key, err.max())
         for key in ("iters", "nz_levels"):
             assert np.array_equal(a[key], b[key]), key
         assert np.abs(a["tau"] - b["tau"]).max() <= 1e-11 * max(1.0, np.abs(b["tau"]).max())
@@ -96,8 +105,11 @@ def test_generated_tasks_through_generic_entry(solver_factory):
     out = s.solve_tasks(tasks, 30, n_inst=n_inst, m_inst=m_inst, p_inst=p_inst)
     ref = s.solve_wbc(d)
     s.synchronize()
-    assert np.array_equal(out["x"].cpu().numpy(), ref["x"].cpu().numpy())
-    assert np.array_equal(out["v"].cpu().numpy()[:, :40], ref["v"].cpu().numpy())
+    # (to rounding: the fused kernel's level-1 QP steps go through eqp_dual16, the generic kernel factors)
+    xa, xb = out["x"].cpu().numpy(), ref["x"].cpu().numpy()
+    va, vb = out["v"].cpu().numpy()[:, :40], ref["v"].cpu().numpy()
+    assert (np.abs(xa - xb) / np.maximum(1.0, np.abs(xb))).max() <= 1e-9
+    assert (np.abs(va - vb) / np.maximum(1.0, np.abs(vb))).max() <= 1e-9
 
 
 def test_oversize_extents_are_clamped(solver_factory):
