@@ -3934,7 +3934,7 @@ __device__ __forceinline__ void hoqp_solve_body(const SolveArgs &a)
 
 	HOQP_STAMP(0);
 	// one level; kc: std::integral_constant<int, level> for a specialised copy, <int, -1> for the run-time loop
-	auto run_level = [&](auto kc, int k_rt) {
+	auto run_level = [&](auto kc, int k_rt) __attribute__((always_inline)) {
 		constexpr int KC = decltype(kc)::value;
 		const int k = (KC >= 0) ? KC : k_rt;
 		HOQP_STAMP(48);	 // loop back-edge
