@@ -47,7 +47,16 @@ extern "C" {
 #define HOQP_STATUS_INFEASIBLE_START 0x02 /* a prior (hard) row was violated when a level started */
 #define HOQP_STATUS_WORKSPACE 0x04	 /* working set outgrew the LDS workspace */
 #define HOQP_STATUS_NONFINITE 0x08	 /* NaN/Inf in the final x, a slack, a level residual, a validity residual or tau */
-#define HOQP_STATUS_UNSUPPORTED 0x10	 /* (unused since Q3 is reproduced for any number of inequality levels) */
+#define HOQP_STATUS_NEAR_SINGULAR 0x10 /* reference semantics: a level's projected block is so close to rank loss
+					  (eps > 3e-8 d^2, d = smallest pivot of its factorization ~ sigma_min) that its
+					  eps-regularised solve must be replayed literally in the reference's LU bases,
+					  and the replay could not be done (a level with more than 12 independent rows,
+					  a QP level with equality rows before it, rank decisions of LU and QR differ).
+					  x then carries the first-order eps correction in the solver's own orthonormal
+					  basis: it deviates from the reference's x by ~ eps / sigma_min^2 of the level's
+					  step, which can exceed the 1e-6 parity bar.  At level 0 (identity basis on
+					  both sides) the bit means eps > 1e-4 d^2.  Informational: x is the solver's
+					  best answer, every other output is consistent with it. */
 #define HOQP_STATUS_BAD_EXTENT 0x20	 /* n_inst / m_inst / p_inst beyond the storage extent: clamped to it */
 #define HOQP_STATUS_BASE_RANK 0x40	 /* hoqp_solve_wbc_batched, reference semantics: [M_fb, -J_c,fb^T] (the floating-base
 					  * block of ho_qp_controller.cpp:351-366) has rank < 6 -- not a physical mass matrix.

@@ -310,6 +310,8 @@ __device__ __forceinline__ void t_upto(int nr, int s, Body body)
 
 // NTA: register blocks of four entries that can be non-zero (vector length nr <= 4 NTA): the loops over a
 // vector's registers stop there -- at the tracking level of the WBC (n_z = 12) that is 3 of 8.
+// (Natural column order -- no pivot search -- was tried for levels 0 and 2 of the fused reference kernel: 0.7 %,
+// the search is not where a step waits; see DESIGN.md, round 3 negatives.)
 template <int NS, int NTA>
 __device__ __forceinline__ int panel_factor_t(double (&x)[NSP][NT], int (&pos)[NSP], int qlo, int qhi, int nr, int k0,
 					      double rtol, const Lds &l, unsigned long long *dbgp)
@@ -2567,7 +2569,9 @@ __device__ __forceinline__ void reg_qr_steps(double (&w)[kRegC + 1], int C, int 
 //            least-squares problem whose residual is ~ |r| / sqrt(eps) = 1e6 |r|, and the error of a QR solve
 //            grows with kappa^2 x residual: 2e-5 relative at sigma_min(M) = 1e-6.  Both stacked systems here
 //            have residuals of the size of r: errors ~ u kappa.)
-// T: scratch for an m x m matrix (m <= nz case).
+// T: scratch for the upper triangle of an m x m matrix, packed by rows (tri_at; m (m + 1) / 2 doubles; m <= nz case).
+__device__ __forceinline__ int tri_at(int i, int j, int m) { return i * m - ((i * (i - 1)) >> 1) + (j - i); }  // j >= i
+
 __device__ __forceinline__ void lds_reg_solve(const ldsd *M, const ldsd *r, int m, int nz, double eps, ldsd *wv, ldsd *zout,
 					      ldsd *T)
 {
@@ -2589,22 +2593,22 @@ __device__ __forceinline__ void lds_reg_solve(const ldsd *M, const ldsd *r, int 
 			w[kRegC] = 0.0;
 		}
 		reg_qr_steps<0>(w, C, nz);
-		// T[i][j] = R(i, j): lane i < m holds row i of R in w[i..m)
+		// T(i, j) = R(i, j), j >= i: lane i < m holds row i of R in w[i..m)
 #pragma unroll
 		for (int j = 0; j < kRegC; ++j)
-			if (j < C && lane < m)
-				T[lane * m + j] = (j >= lane) ? w[j] : 0.0;
+			if (j < C && lane < m && j >= lane)
+				T[tri_at(lane, j, m)] = w[j];
 		wave_sync();
 		// ---- stacked system [R'; sqrt(eps) I] y = [r; 0]: lane i < m holds row i of R' ----
 		{
 			double ld_[kRegC + 1];
 #pragma unroll
-			for (int j = 0; j < kRegC; ++j)
-				ld_[j] = T[((j < C) ? j : 0) * m + (lane < m ? lane : 0)];
+			for (int j = 0; j < kRegC; ++j)  // R'(lane, j) = R(j, lane), zero for j > lane
+				ld_[j] = T[(j < C && lane < m && j <= lane) ? tri_at(j, lane, m) : 0];
 			ld_[kRegC] = r[lane < m ? lane : 0];
 #pragma unroll
 			for (int j = 0; j < kRegC; ++j)
-				w[j] = (j < C) ? ((lane < m) ? ld_[j] : ((lane - m == j) ? se : 0.0)) : 0.0;
+				w[j] = (j < C) ? ((lane < m) ? ((j <= lane) ? ld_[j] : 0.0) : ((lane - m == j) ? se : 0.0)) : 0.0;
 			w[kRegC] = (lane < m) ? ld_[kRegC] : 0.0;
 		}
 		reg_qr_steps<0>(w, C, 2 * m);
@@ -2635,9 +2639,11 @@ __device__ __forceinline__ void lds_reg_solve(const ldsd *M, const ldsd *r, int 
 	if (dual) {
 		// w = R^-1 y (R in T, one row per lane), then z = M' w
 		double acc2 = wv[lane < m ? lane : 0];
+		const int lr = lane < m ? lane : 0;
+		const double rdiag = T[tri_at(lr, lr, m)];
 		for (int i = m - 1; i >= 0; --i) {
-			const double si = readlane_d(acc2 / T[(lane < m ? lane : 0) * m + (lane < m ? lane : 0)], i);
-			acc2 = fma(-T[(lane < m ? lane : 0) * m + i], si, acc2);
+			const double si = readlane_d(acc2 / rdiag, i);
+			acc2 = fma(-((i >= lr) ? T[tri_at(lr, i >= lr ? i : lr, m)] : 0.0), si, acc2);
 			wave_sync();
 			if (lane == 0)
 				wv[i] = si;
@@ -2722,7 +2728,7 @@ __device__ __forceinline__ bool ref_replay(const SolveArgs &a, const Lds &l, int
 		// MK: M (mj x nzr; for j < k its LU factors, then U11^-1 U12 inside them) and, at j == k, the m x m factor of
 		// lds_reg_solve.  The bases live in ZB: from the identity the kernel matrix IS the new basis, afterwards
 		// the basis is updated in place (lds_basis_update).
-		if (mj * nzr + (j < k ? 0 : cmin * cmin) > tvcap || cmin > kRegC || mj + nzr > kWave || nzr - cmin > MAXQ)
+		if (mj * nzr + (j < k ? 0 : (cmin * (cmin + 1)) / 2) > tvcap || cmin > kRegC || mj + nzr > kWave || nzr - cmin > MAXQ)
 			return false;
 		{
 			// M = A_j Zr -> TV (stride nzr),  r = b_j - A_j xr -> l.rhs
@@ -3179,7 +3185,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l_in,
 			t_upto(nz, s, [&](int t, bool on) { x[sl][t] = sel(on && pos[sl] == -1, x[sl][t]); });
 		}
 		wave_sync();  // every column is in registers before TV is reused as the reflector store
-		rank = uni(panel_factor<(WBC && GATE && !HARD && KC >= 0)>(x, pos, nslot, 0, m, nz, 0, kEpsMach * (double)max(m, nz), l, HOQP_DBGP));
+		rank = uni(panel_factor<COMPACT>(x, pos, nslot, 0, m, nz, 0, kEpsMach * (double)max(m, nz), l, HOQP_DBGP));
 		HOQP_STAMP(2);
 		if (COMPACT && KC == 0 && rank != kNB) {
 			// [M_fb, -J_c,fb^T] without full row rank (not a physical mass matrix): more than 24 free
@@ -3641,16 +3647,24 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l_in,
 		if (consider && m > 0)
 			st.replay_ok = 0;
 	}
-#ifndef HOQP_NO_REPLAY
-	if (__builtin_expect(a.eps != 0.0 && !consider && !keep_rows && st.replay_ok && m > 0 && rank > 0 && k > 0 &&
-				     a.eps > kReplayTau * dmin_level * dmin_level,
+	// (level 0: both sides work in the identity basis, the first-order correction is then exact to (eps / sigma^2)^2
+	// and there is nothing to replay; it is only reported when even that is in reach of the parity bar)
+	if (__builtin_expect(a.eps != 0.0 && m > 0 && rank > 0 &&
+				     a.eps > (k > 0 ? kReplayTau : 1e-4) * dmin_level * dmin_level,
 			     0)) {
-		wave_sync();
-		double res2 = 0.0;
-		if (ref_replay<WBC, (COMPACT ? 24 : NR)>(a, l, inst, k, n, nz, wx, jc, &res2))
-			level_res2 = res2 + res_const;
-	}
+		bool replayed = false;
+#ifndef HOQP_NO_REPLAY
+		if (!consider && !keep_rows && st.replay_ok && k > 0) {
+			wave_sync();
+			double res2 = 0.0;
+			replayed = ref_replay<WBC, (COMPACT ? 24 : NR)>(a, l, inst, k, n, nz, wx, jc, &res2);
+			if (replayed)
+				level_res2 = res2 + res_const;
+		}
 #endif
+		if (!replayed)
+			st.status |= HOQP_STATUS_NEAR_SINGULAR;  // first-order eps correction only (include/hoqp.h)
+	}
 	if (lane == 0) {
 		if (a.out.level_res)
 			a.out.level_res[(size_t)inst * a.L + k] = sqrt(level_res2);

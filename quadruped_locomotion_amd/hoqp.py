@@ -29,6 +29,7 @@ STATUS_MAX_ITER = 0x01
 STATUS_INFEASIBLE_START = 0x02
 STATUS_WORKSPACE = 0x04
 STATUS_NONFINITE = 0x08
+STATUS_NEAR_SINGULAR = 0x10
 STATUS_BAD_EXTENT = 0x20
 STATUS_BASE_RANK = 0x40
 NOALLOC_MAX_BATCH = 256

@@ -201,3 +201,79 @@ def test_near_singular_family(solver_factory, oracle):
         j = int(e.argmax())
         assert e.max() <= RTOL, f"{key}: {e.max():.3e} at delta = {delta[j]:.2e}, sigma_min = {smin[j]:.2e}, dmin = {d3[j]:.2e}"
     _flags_and_masks(o, ref, inp, oracle)
+
+
+def _level_sigmas(inp, i):
+    """(sigma_min, sigma_max) of A_k Z_{k-1} for the equality levels 0, 2, 3 of state i (orthonormal bases)."""
+    import scipy.linalg as sl
+
+    ct = inp["contact"][i].astype(bool)
+    cl = [leg for leg in range(4) if ct[leg]]
+    sw = [leg for leg in range(4) if not ct[leg]]
+    nc = len(cl)
+    M, Jf, Jb = inp["M"][i], inp["Jfoot"][i], inp["Jb"][i]
+    Jc = np.concatenate([Jf[leg] for leg in cl], 0)
+    A0 = np.concatenate([M[:6, :], -Jc[:, :6].T], 1)
+    A2 = np.concatenate([Jc, np.zeros((3 * nc, 3 * nc))], 1)
+    A3 = np.concatenate([Jb[3:6], Jb[0:3]] + [Jf[leg] for leg in sw], 0)
+    A3 = np.concatenate([A3, np.zeros((A3.shape[0], 3 * nc))], 1)
+    Z = np.eye(18 + 3 * nc)
+    out = []
+    for A in (A0, A2, A3):
+        sv = np.linalg.svd(A @ Z, compute_uv=False)
+        out.append((sv[-1], sv[0]))
+        Z = Z @ sl.null_space(A @ Z)
+    return out
+
+
+@pytest.mark.parametrize("kind", ["knee", "merged"])
+def test_near_singular_contact_legs(solver_factory, oracle, kind):
+    """Two more constructed families, on four-contact states.
+    "knee":   the knee of a CONTACT leg is straightened: the contact Jacobian keeps its rank (the base columns), but
+              the base-motion level (level 3) behind it loses the direction along the straight leg.
+    "merged": the foot Jacobian of one contact leg is moved onto that of another, J_b <- J_a + delta (J_b - J_a)
+              (inputs of the C ABI are plain arrays; the oracle sees the same ones), so that the no-contact-motion
+              level (level 2) has sigma_min ~ 0.1 delta, swept over 1e-5 ... 1e-1: the replay of a 12 x 24 level,
+              the largest block the fused kernel's compact LDS layout has to replay (the triangular factor of its
+              regularised solve is stored packed to fit)."""
+    N = 256
+    st = am.sample_states(N, 9753, "stance")
+    delta = np.logspace(-4.0, 0.0, N)
+    if kind == "knee":
+        for i in range(N):
+            leg = i % 4
+            st["q"][i, 7 + 8 + leg] = delta[i] * (-1.0 if leg < 2 else 1.0)
+    inp = am.make_wbc_inputs(st)
+    if kind == "merged":
+        for i in range(N):
+            a = i % 4
+            b = (a + 1 + (i // 4) % 3) % 4
+            inp["Jfoot"][i, b] = inp["Jfoot"][i, a] + delta[i] * (inp["Jfoot"][i, b] - inp["Jfoot"][i, a])
+    sig = np.array([_level_sigmas(inp, i) for i in range(N)])        # [N, 3, 2]
+    smin = sig[:, 2 if kind == "knee" else 1, 0]
+    thr_replay = np.sqrt(EPS / K_REPLAY_TAU)
+    assert smin.min() < 3e-5 and (smin < 0.3 * thr_replay).sum() >= 32, smin.min()
+    if kind == "merged":
+        assert (smin > 3.0 * thr_replay).sum() >= 32
+    s = solver_factory("reference")
+    out = s.solve_wbc(s.to_device(inp))
+    s.synchronize()
+    o = {k: v.cpu().numpy() for k, v in out.items()}
+    ref, rc = oracle.wbc_solve_batch(inp, oracle.default_cfg("reference"), oracle.default_wbc_params("reference"),
+                                     threads=16)
+    assert rc == 0
+    assert np.all(o["status"] == 0)
+    # the rounding floor of test_near_singular_family, with the worst level's conditioning
+    u = 2.0 ** -53
+    kappa = (sig[:, :, 1] / np.sqrt(sig[:, :, 0] ** 2 + EPS)).max(axis=1)
+    floor = 4.0 * u * kappa * np.abs(ref["x"]).max(axis=1)
+    assert (floor < 1e-7).sum() >= N // 2
+    xerr = np.abs(o["x"] - ref["x"])
+    assert np.all(xerr.max(axis=1) <= RTOL * np.maximum(1.0, np.abs(ref["x"]).max(axis=1))), "x, norm-wise"
+    for key, width in (("x", 30), ("qdd", 12), ("tau", 12), ("v", 40), ("level_res", 5)):
+        r = ref[key][:, :width] if key == "v" else ref[key]
+        scale = 100.0 if key in ("tau", "v") else 1.0
+        e = (np.abs(o[key] - r) / (np.maximum(1.0, np.abs(r)) + scale * floor[:, None] / RTOL)).reshape(N, -1).max(axis=1)
+        j = int(e.argmax())
+        assert e.max() <= RTOL, f"{key}: {e.max():.3e} at delta = {delta[j]:.2e}, sigma_min = {smin[j]:.2e}"
+    _flags_and_masks(o, ref, inp, oracle)
