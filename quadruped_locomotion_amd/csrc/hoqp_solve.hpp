@@ -1535,7 +1535,7 @@ __device__ __forceinline__ void project_task_mfma(Src &src, int rows, int nz, co
 // Level 0 of the fused entry (ConstructFloatingBaseEomTask, ho_qp_controller.cpp:351-366): Z = I and x = 0
 // (InitPrevProblemValuesToDefault, ho_qp_problem.cpp:119-128), so the projected block is the block itself:
 // A = [M_fb, -J_c,fb^T], r = b = -h_fb.  One column per lane, three rows each.
-__device__ __forceinline__ void wbc_project_level0(const WbcCtx &wx, int ld, const Lds &l)
+__device__ __forceinline__ void wbc_project_level0(const WbcCtx &wx, int ld, const Lds &l, ldsd *dstM, ldsd *dstr)
 {
 	const int lane = lane_id(), c = lane & 31, r2 = lane >> 5;
 	const int jc0 = wbc_jcoff(wx, c);
@@ -1554,9 +1554,9 @@ __device__ __forceinline__ void wbc_project_level0(const WbcCtx &wx, int ld, con
 #pragma unroll
 	for (int j = 0; j < 3; ++j) {
 		const int r = r2 + 2 * j;
-		st_if(c < wx.n, l.TV + r * ld + c, l.dump + lane, ism ? v[j] : 0.0 - v[j]);
+		st_if(c < wx.n, dstM + r * ld + c, l.dump + lane, ism ? v[j] : 0.0 - v[j]);
 	}
-	st_if(lane < kNB, l.rhs + lane, l.dump + lane, 0.0 - hv);
+	st_if(lane < kNB, dstr + lane, l.dump + lane, 0.0 - hv);
 	wave_sync();
 }
 
@@ -2421,7 +2421,35 @@ __device__ __forceinline__ void lds_lu_kernel(const ldsd *M, int c, int rank, co
 	const int dk = c - rank;
 	// rows in pivot POSITION order first (X = U11^-1 U12 by back substitution, one kernel column per
 	// lane, the loads of a row's terms in flight together), scattered to the original rows at the end
-	if (lane < dk) {
+	if (rank <= 12) {
+		// (as in lds_basis_update: the lane's column of X in registers, a row of U11 read as a block)
+		double xc[12];
+#pragma unroll
+		for (int i = 0; i < 12; ++i)
+			xc[i] = 0.0;
+		const int cl = rank + (lane < dk ? lane : 0);
+#pragma unroll
+		for (int i = 11; i >= 0; --i) {
+			if (i >= rank)
+				continue;
+			double u[12];
+#pragma unroll
+			for (int j = 0; j < 12; ++j)
+				u[j] = M[i * c + ((j >= i && j < rank) ? j : i)];
+			double sacc = M[i * c + cl];
+#pragma unroll
+			for (int j = 0; j < 12; ++j)
+				pin(u[j]);
+#pragma unroll
+			for (int j = 0; j < 12; ++j)
+				sacc = (j > i && j < rank) ? fma(-u[j], xc[j], sacc) : sacc;
+			xc[i] = sacc / u[i];
+		}
+#pragma unroll
+		for (int i = 0; i < 12; ++i)
+			if (i < rank && lane < dk)
+				K[i * dk + lane] = xc[i];
+	} else if (lane < dk) {
 		for (int i = rank - 1; i >= 0; --i) {
 			double sacc = M[i * c + rank + lane];
 			for (int j0 = i + 1; j0 < rank; j0 += 4) {
@@ -2485,7 +2513,37 @@ __device__ __forceinline__ void lds_basis_update(ldsd *Z, int n, int nzr, int ra
 	const int dk = nzr - rank;
 	if (lane < nzr)
 		ipos[cperm[lane]] = lane;
-	if (lane < dk) {
+	if (rank <= 12) {
+		// one column of X per lane, held in registers; row i of U11 is read as a block (uniform addresses,
+		// the loads of a row in flight together) -- the same terms in the same order as the loop below
+		double xc[12];
+#pragma unroll
+		for (int i = 0; i < 12; ++i)
+			xc[i] = 0.0;
+		const int cl = rank + (lane < dk ? lane : 0);
+#pragma unroll
+		for (int i = 11; i >= 0; --i) {
+			if (i >= rank)
+				continue;
+			double u[12];
+#pragma unroll
+			for (int j = 0; j < 12; ++j)
+				u[j] = LU[i * nzr + ((j >= i && j < rank) ? j : i)];
+			double sacc = LU[i * nzr + cl];
+#pragma unroll
+			for (int j = 0; j < 12; ++j)
+				pin(u[j]);
+#pragma unroll
+			for (int j = 0; j < 12; ++j)
+				sacc = (j > i && j < rank) ? fma(-u[j], xc[j], sacc) : sacc;
+			xc[i] = sacc / u[i];
+		}
+		wave_sync();
+#pragma unroll
+		for (int i = 0; i < 12; ++i)
+			if (i < rank && lane < dk)
+				LU[i * nzr + rank + lane] = xc[i];
+	} else if (lane < dk) {
 		for (int i = rank - 1; i >= 0; --i) {
 			double sacc = LU[i * nzr + rank + lane];
 			for (int j = i + 1; j < rank; ++j)
@@ -2530,10 +2588,10 @@ __device__ __forceinline__ void lds_basis_update(ldsd *Z, int n, int nzr, int ra
 constexpr int kRegC = 12;  // columns of the stacked system held in registers (WBC: <= 12)
 // Householder steps K.. of the lane-per-row QR (recursion = full unrolling with the step index a
 // compile-time constant, so that the dot products of one step are reduced together, wave_sum_n)
-template <int K>
-__device__ __forceinline__ void reg_qr_steps(double (&w)[kRegC + 1], int C, int R)
+template <int K, int RC>
+__device__ __forceinline__ void reg_qr_steps(double (&w)[RC + 1], int C, int R)
 {
-	if constexpr (K < kRegC) {
+	if constexpr (K < RC) {
 		if (K < C) {
 			const int lane = lane_id();
 			const bool on = lane >= K && lane < R;
@@ -2544,24 +2602,24 @@ __device__ __forceinline__ void reg_qr_steps(double (&w)[kRegC + 1], int C, int 
 				const double beta = (alpha >= 0.0) ? -nrm : nrm;
 				v = (lane == K) ? alpha - beta : v;
 				const double tk = 1.0 / (nrm * (nrm + fabs(alpha)));
-				double d[kRegC - K];  // columns K+1 .. kRegC-1 and the right-hand side (slot kRegC)
+				double d[RC - K];  // columns K+1 .. RC-1 and the right-hand side (slot RC)
 #pragma unroll
-				for (int j = K + 1; j <= kRegC; ++j)
+				for (int j = K + 1; j <= RC; ++j)
 					d[j - K - 1] = v * w[j];
 				wave_sum_n(d);
 #pragma unroll
-				for (int j = K + 1; j <= kRegC; ++j)
+				for (int j = K + 1; j <= RC; ++j)
 					w[j] = fma(-d[j - K - 1] * tk, v, w[j]);
 				w[K] = (lane == K) ? beta : w[K];
 			}
-			reg_qr_steps<K + 1>(w, C, R);
+			reg_qr_steps<K + 1, RC>(w, C, R);
 		}
 	}
 }
 
 // zout (nz) = argmin |M z - r|^2 + eps |z|^2, M (m x nz, stride nz) and r in LDS, by Householder QR,
-// one row per lane, the row held in registers (C = min(m, nz) <= kRegC columns plus the right-hand side;
-// the column loops are unrolled over kRegC with wave-uniform guards):
+// one row per lane, the row held in registers (C = min(m, nz) <= RC columns plus the right-hand side;
+// the column loops are unrolled over RC with wave-uniform guards):
 //   m > nz:  the stacked system [M; sqrt(eps) I] z = [r; 0].
 //   m <= nz: z lies in range(M') = range(Q) of the QR M' = Q R, so z = Q y = M' R^-1 y with
 //            y = argmin |R' y - r|^2 + eps |y|^2, again a stacked system [R'; sqrt(eps) I] y = [r; 0] (2m x m).
@@ -2572,6 +2630,7 @@ __device__ __forceinline__ void reg_qr_steps(double (&w)[kRegC + 1], int C, int 
 // T: scratch for the upper triangle of an m x m matrix, packed by rows (tri_at; m (m + 1) / 2 doubles; m <= nz case).
 __device__ __forceinline__ int tri_at(int i, int j, int m) { return i * m - ((i * (i - 1)) >> 1) + (j - i); }  // j >= i
 
+template <int RC>
 __device__ __forceinline__ void lds_reg_solve(const ldsd *M, const ldsd *r, int m, int nz, double eps, ldsd *wv, ldsd *zout,
 					      ldsd *T)
 {
@@ -2579,55 +2638,55 @@ __device__ __forceinline__ void lds_reg_solve(const ldsd *M, const ldsd *r, int 
 	const bool dual = m <= nz;
 	const int C = dual ? m : nz;
 	const double se = sqrt(eps);
-	double w[kRegC + 1];
+	double w[RC + 1];
 	if (dual) {
 		// ---- R of M' = Q R: lane q < nz holds row q of M' ----
 		{
-			double ld_[kRegC];
+			double ld_[RC];
 #pragma unroll
-			for (int j = 0; j < kRegC; ++j)
+			for (int j = 0; j < RC; ++j)
 				ld_[j] = M[((j < C) ? j : 0) * nz + (lane < nz ? lane : 0)];
 #pragma unroll
-			for (int j = 0; j < kRegC; ++j)
+			for (int j = 0; j < RC; ++j)
 				w[j] = (j < C && lane < nz) ? ld_[j] : 0.0;
-			w[kRegC] = 0.0;
+			w[RC] = 0.0;
 		}
-		reg_qr_steps<0>(w, C, nz);
+		reg_qr_steps<0, RC>(w, C, nz);
 		// T(i, j) = R(i, j), j >= i: lane i < m holds row i of R in w[i..m)
 #pragma unroll
-		for (int j = 0; j < kRegC; ++j)
+		for (int j = 0; j < RC; ++j)
 			if (j < C && lane < m && j >= lane)
 				T[tri_at(lane, j, m)] = w[j];
 		wave_sync();
 		// ---- stacked system [R'; sqrt(eps) I] y = [r; 0]: lane i < m holds row i of R' ----
 		{
-			double ld_[kRegC + 1];
+			double ld_[RC + 1];
 #pragma unroll
-			for (int j = 0; j < kRegC; ++j)  // R'(lane, j) = R(j, lane), zero for j > lane
+			for (int j = 0; j < RC; ++j)  // R'(lane, j) = R(j, lane), zero for j > lane
 				ld_[j] = T[(j < C && lane < m && j <= lane) ? tri_at(j, lane, m) : 0];
-			ld_[kRegC] = r[lane < m ? lane : 0];
+			ld_[RC] = r[lane < m ? lane : 0];
 #pragma unroll
-			for (int j = 0; j < kRegC; ++j)
+			for (int j = 0; j < RC; ++j)
 				w[j] = (j < C) ? ((lane < m) ? ((j <= lane) ? ld_[j] : 0.0) : ((lane - m == j) ? se : 0.0)) : 0.0;
-			w[kRegC] = (lane < m) ? ld_[kRegC] : 0.0;
+			w[RC] = (lane < m) ? ld_[RC] : 0.0;
 		}
-		reg_qr_steps<0>(w, C, 2 * m);
+		reg_qr_steps<0, RC>(w, C, 2 * m);
 	} else {
 		// the lane's row: all loads first (clamped addresses), then the selects
-		double ld_[kRegC + 1];
+		double ld_[RC + 1];
 #pragma unroll
-		for (int j = 0; j <= kRegC; ++j)
+		for (int j = 0; j <= RC; ++j)
 			ld_[j] = (j < C) ? M[(lane < m ? lane : 0) * nz + ((j < C) ? j : 0)] : r[lane < m ? lane : 0];
 #pragma unroll
-		for (int j = 0; j < kRegC; ++j)
+		for (int j = 0; j < RC; ++j)
 			w[j] = (j < C) ? ((lane < m) ? ld_[j] : ((lane - m == j && lane < m + nz) ? se : 0.0)) : 0.0;
-		w[kRegC] = (lane < m) ? ld_[kRegC] : 0.0;
-		reg_qr_steps<0>(w, C, m + nz);
+		w[RC] = (lane < m) ? ld_[RC] : 0.0;
+		reg_qr_steps<0, RC>(w, C, m + nz);
 	}
 	// back substitution: lane i holds row i of the triangular factor and the transformed right-hand side
-	double acc = w[kRegC];
+	double acc = w[RC];
 #pragma unroll
-	for (int i = kRegC - 1; i >= 0; --i) {
+	for (int i = RC - 1; i >= 0; --i) {
 		if (i >= C)
 			continue;
 		const double si = readlane_d(acc / w[i], i);
@@ -2730,7 +2789,10 @@ __device__ __forceinline__ bool ref_replay(const SolveArgs &a, const Lds &l, int
 		// the basis is updated in place (lds_basis_update).
 		if (mj * nzr + (j < k ? 0 : (cmin * (cmin + 1)) / 2) > tvcap || cmin > kRegC || mj + nzr > kWave || nzr - cmin > MAXQ)
 			return false;
-		{
+		if (WBC && j == 0 && zident && j < k) {
+			// from the identity the projected block is the block itself (the right-hand side is not used: j < k)
+			wbc_project_level0(wx, nzr, l, MK, l.rhs);
+		} else {
 			// M = A_j Zr -> TV (stride nzr),  r = b_j - A_j xr -> l.rhs
 			double bm[NR / 4][2];
 			load_bm_from(bm, n, nzr, nzr, Zr, xr, zident);
@@ -2757,7 +2819,10 @@ __device__ __forceinline__ bool ref_replay(const SolveArgs &a, const Lds &l, int
 		}
 		RSTAMP(33);
 		if (j == k) {
-		lds_reg_solve(MK, l.rhs, mj, nzr, a.eps, wv, zv, MK + mj * nzr);
+		if (cmin <= 6)  // (the tracking level of a stance state: half the columns, half the reductions)
+			lds_reg_solve<6>(MK, l.rhs, mj, nzr, a.eps, wv, zv, MK + mj * nzr);
+		else
+			lds_reg_solve<kRegC>(MK, l.rhs, mj, nzr, a.eps, wv, zv, MK + mj * nzr);
 		RSTAMP(34);
 		{  // |A_k x_k - b_k|^2 at the regularised optimum
 			double ri = 0.0;
@@ -2811,7 +2876,10 @@ __device__ __forceinline__ bool ref_replay(const SolveArgs &a, const Lds &l, int
 				RSTAMP(37);
 			} else {
 				RSTAMP(37);
-				lds_basis_update<MAXQ>(ZB, n, nzr, rank, l.colpos, MK, l.pivlane);
+				if (MAXQ > 12 && dk <= 12)  // (the WBC: 12 free coordinates are left behind the contact level)
+					lds_basis_update<12>(ZB, n, nzr, rank, l.colpos, MK, l.pivlane);
+				else
+					lds_basis_update<MAXQ>(ZB, n, nzr, rank, l.colpos, MK, l.pivlane);
 			}
 			wave_sync();
 			RSTAMP(38);
@@ -2925,7 +2993,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l_in,
 			}
 		} else if (WBC && k == 0) {
 			if (m > 0 && doA)
-				wbc_project_level0(wx, ldt, l);
+				wbc_project_level0(wx, ldt, l, l.TV, l.rhs);
 		} else if (WBC) {  // fused entry (n <= 30: always the matrix-core path)
 			double bm[NR / 4][2];
 #ifdef HOQP_PROFILE
