@@ -48,8 +48,10 @@ template <int CTRL>
 __device__ __forceinline__ double dpp_d(double v)
 {
 	int lo = __double2loint(v), hi = __double2hiint(v);
-	lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-	hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+	// mov_dpp (destination undefined before the move) instead of update_dpp(old = v): every lane of the
+	// patterns used here has a valid source, and the tied "old" operand cost a v_mov copy per half
+	lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+	hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
 	return __hiloint2double(hi, lo);
 }
 
@@ -120,7 +122,7 @@ __device__ __forceinline__ double wave_argmin(double v, int payload, int *idx)
 template <int CTRL>
 __device__ __forceinline__ unsigned dpp_u(unsigned v)
 {
-	return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+	return (unsigned)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true);
 }
 
 // Lane holding the largest 32-bit key, keys identical within a quad, 0 = "not a candidate";

@@ -93,7 +93,15 @@ struct LdsOff {
 	int Z, x, G, g, vs, s, c, TV, S, BL, r0, rho, a0, tau, rdiag, rhs, X, tmp, dump, b3, pivlane, W, xlane, colpos, vlist, total;
 };
 
-__host__ __device__ inline LdsOff lds_offsets(const SolveArgs &a)
+// the extents the layout depends on
+struct LdsDims {
+	int n, ld, Ptot, mmax, use_bl, compact;
+};
+// the fused WBC entry under reference semantics (compact layout): n = 30 storage columns, 40 inequality rows.
+// In the kernel these are compile-time constants, so every LDS array sits at a literal offset.
+constexpr LdsDims kCompactDims = {30, 0, 40, 0, 0, 1};
+
+__host__ __device__ inline LdsOff lds_offsets(const LdsDims &a)
 {
 	LdsOff o;
 	int off = 0;
@@ -142,6 +150,14 @@ __host__ __device__ inline LdsOff lds_offsets(const SolveArgs &a)
 	return o;
 }
 
+__host__ __device__ inline LdsOff lds_offsets(const SolveArgs &a)
+{
+	if (a.compact)
+		return lds_offsets(kCompactDims);
+	const LdsDims d = {a.n, a.ld, a.Ptot, a.mmax, a.use_bl, 0};
+	return lds_offsets(d);
+}
+
 #ifdef __HIP_DEVICE_COMPILE__
 struct Lds {
 	ldsd *Z, *x, *G, *g, *vs, *s, *c, *TV, *S, *BL, *r0, *rho, *a0, *tau, *rdiag, *rhs, *X, *tmp, *dump, *b3;
@@ -154,9 +170,10 @@ struct Lds {
 	unsigned long long *dbgp;  // HOQP_PROFILE builds: this instance's cycle-stamp slots (else null)
 };
 
+template <bool CK = false>  // CK: the kernel of the compact layout (offsets are literals)
 __device__ __forceinline__ Lds lds_bind(const SolveArgs &a, HOQP_LDS char *base)
 {
-	const LdsOff o = lds_offsets(a);
+	const LdsOff o = CK ? lds_offsets(kCompactDims) : lds_offsets(a);
 	Lds l;
 	l.Z = (ldsd *)(base + o.Z);
 	l.x = (ldsd *)(base + o.x);
@@ -184,8 +201,8 @@ __device__ __forceinline__ Lds lds_bind(const SolveArgs &a, HOQP_LDS char *base)
 	l.colpos = (ldsi *)(base + o.colpos);
 	l.vlist = (ldsi *)(base + o.vlist);
 	l.ldv = LDV;
-	l.xrows = a.compact ? kCXrows : XROWS;
-	if (a.compact) {
+	l.xrows = (CK || a.compact) ? kCXrows : XROWS;
+	if (CK || a.compact) {
 		l.rpZ = l.G;
 		l.rpZcap = kCReplayZ;
 		l.rpM = l.G + kCReplayZ;
@@ -3942,7 +3959,7 @@ __device__ __forceinline__ void hoqp_solve_body(const SolveArgs &a)
 {
 #ifdef __HIP_DEVICE_COMPILE__
 	extern __shared__ __align__(16) char smem[];
-	const Lds l = lds_bind(a, (HOQP_LDS char *)smem);
+	const Lds l = lds_bind<(WBC && GATE && !HARD)>(a, (HOQP_LDS char *)smem);
 	const int lane = lane_id();
 	const int inst = blockIdx.x;
 	if (inst >= a.batch)
