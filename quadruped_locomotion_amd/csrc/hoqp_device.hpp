@@ -21,7 +21,18 @@ typedef double d2v __attribute__((ext_vector_type(2)));
 typedef HOQP_LDS d2v ldsd2;
 constexpr double kEpsMach = 2.220446049250313e-16;
 
-__device__ __forceinline__ int lane_id() { return threadIdx.x; }
+// The lane index is handed out through an empty volatile asm, so the compiler cannot see that two routines
+// derive their (s, c) maps, masks and LDS addresses from the same value.  Without it the optimizer shares and
+// hoists every lane-derived expression of the one big kernel function: hundreds of values (the comparison masks
+// alone are an SGPR pair each) that live from the kernel's head to their last use -- 611 SGPR and 91 VGPR spills,
+// 272 B of scratch per lane in the fused reference kernel.  Recomputing them per routine costs a few integer
+// instructions and leaves 247 VGPRs, no scratch, 85 SGPR spills: +9 %.
+__device__ __forceinline__ int lane_id()
+{
+	int l = threadIdx.x;
+	asm volatile("" : "+v"(l));
+	return l;
+}
 
 // Ordering point between LDS writes and reads of different lanes.  The workgroup is a single
 // wavefront and the LDS pipeline executes one wavefront's instructions in issue order, so
