@@ -20,7 +20,9 @@ cd $ROOT
 # what FETCH_SIZE / WRITE_SIZE report for this kernel's access pattern (factors applied by the summary)
 bash tools/calib/fetch_calib.sh > gpurun_out/rocprof/calib.log 2>&1 || echo "calibration failed"
 python3 tools/profile_summarize.py gpurun_out/rocprof gpurun_out/rocprof/summary
-# full bench line (with the CPU baseline) and the per-section cycle profile of the profiling build
+# full bench line (with the CPU baseline) and the per-section cycle profile of the profiling build; the bench
+# line carries the traffic just measured (bench.py reads it from profiles/, keyed by the library's SHA-256)
+cp gpurun_out/rocprof/summary_pmc_traffic.json profiles/r03_pmc_traffic.json
 timeout -k 10 400 python3 bench.py > gpurun_out/rocprof/bench_full.json
 HOQP_DBG=1 HOQP_LIB=$PWD/quadruped_locomotion_amd/libhoqp_hip_prof.so timeout -k 10 200 python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 --latency-batches 2 2> gpurun_out/rocprof/sections_reference.txt > /dev/null
 HOQP_DBG=1 HOQP_LIB=$PWD/quadruped_locomotion_amd/libhoqp_hip_prof.so timeout -k 10 200 python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 --latency-batches 2 --mode paper 2> gpurun_out/rocprof/sections_paper.txt > /dev/null
