@@ -358,6 +358,39 @@ def test_nullspace_projector_and_lexicographic_optimality(solver_factory, oracle
             Zprev, xprev = Z, x
 
 
+def test_near_singular_status_bit(solver_factory, oracle):
+    """HOQP_STATUS_NEAR_SINGULAR (include/hoqp.h): a level that needs the literal replay of the reference and
+    cannot get it says so.  Level 1 here has 14 independent rows (the replay holds at most 12 in registers) of
+    which one is delta away from a combination of the others: for delta <= 1e-4 (eps / sigma_min^2 >= 1e-4) the
+    bit must be set, for delta = 1 it must not; instances without the bit meet the parity bar, every x is finite."""
+    import torch
+    from quadruped_locomotion_amd import hoqp
+
+    rng = np.random.default_rng(77)
+    B, n = 32, 20
+    delta = np.where(np.arange(B) % 2 == 0, 10.0 ** (-4.0 - (np.arange(B) % 6) / 4.0), 1.0)
+    A0, b0 = rng.normal(size=(B, 2, n)), rng.normal(size=(B, 2))
+    A1, b1 = rng.normal(size=(B, 14, n)), rng.normal(size=(B, 14))
+    for i in range(B):
+        w = rng.normal(size=13)
+        A1[i, 13] = w @ A1[i, :13] / np.linalg.norm(w) + delta[i] * A1[i, 13]
+    A2, b2 = rng.normal(size=(B, 6, n)), rng.normal(size=(B, 6))
+    tasks = [{"A": A0, "b": b0}, {"A": A1, "b": b1}, {"A": A2, "b": b2}]
+    s = solver_factory("reference")
+    out = s.solve_tasks([{k: torch.as_tensor(v).contiguous().cuda() for k, v in t.items()} for t in tasks], n)
+    s.synchronize()
+    st, x = out["status"].cpu().numpy(), out["x"].cpu().numpy()
+    assert np.all(np.isfinite(x))
+    small = delta <= 1e-4
+    assert np.all(st[small] == hoqp.STATUS_NEAR_SINGULAR), st[small]
+    assert np.all(st[~small] == 0), st[~small]
+    cfg = oracle.default_cfg("reference")
+    for i in np.nonzero(~small)[0]:
+        r = oracle.solve_tasks([{k: v[i] for k, v in t.items()} for t in tasks], n, cfg)
+        assert r["rc"] == 0
+        _close(x[i, :n], r["x_levels"][-1], f"x inst {i}")
+
+
 def _lowrank(rng, B, m, n, r):
     """m rows of rank r (every row a random combination of r base rows)."""
     base = rng.normal(size=(B, r, n))
