@@ -530,9 +530,9 @@ static int launch_solve(hoqp_handle *h, SolveArgs &a, hipStream_t s, bool wbc, b
 #endif
 	a.ld = lds_leading_dim(a.n);
 	// the fused WBC entry under reference semantics runs hoqp_solve_wbc_ref_kernel on the compact LDS layout
-	a.compact = (wbc && !a.any_hard) ? 1 : 0;
-	if (a.compact && (a.n != kCompactDims.n || a.Ptot != kCompactDims.Ptot))
-		return fail(h, -1, "internal: the compact layout is compiled for n = 30, 40 inequality rows");
+	a.compact = wbc ? (a.any_hard ? 2 : 1) : 0;
+	if (a.compact && (a.n != kCompactDims.n || a.Ptot != kCompactDims.Ptot || a.mmax > kPBlRows))
+		return fail(h, -1, "internal: the compact layouts are compiled for n = 30, 40 inequality rows");
 	size_t lds = (size_t)lds_offsets(a).total;
 	if ((int)lds > h->max_lds)
 		return fail(h, -5, "LDS workspace " + std::to_string(lds) + " B exceeds the device limit");
@@ -541,7 +541,7 @@ static int launch_solve(hoqp_handle *h, SolveArgs &a, hipStream_t s, bool wbc, b
 	// it is either <gated, no hard rows> or <ungated, hard rows>
 	void (*kern)(const SolveArgs);
 	if (wbc)
-		kern = !a.any_hard ? hoqp_solve_wbc_ref_kernel : hoqp_solve_kernel<false, true, true>;
+		kern = !a.any_hard ? hoqp_solve_wbc_ref_kernel : hoqp_solve_wbc_paper_kernel;
 	else
 		kern = !a.any_hard ? hoqp_solve_kernel<true, false, false>
 				   : (a.gate_prior ? hoqp_solve_kernel<true, true, false> : hoqp_solve_kernel<false, true, false>);

@@ -100,6 +100,12 @@ struct LdsDims {
 // the fused WBC entry under reference semantics (compact layout): n = 30 storage columns, 40 inequality rows.
 // In the kernel these are compile-time constants, so every LDS array sits at a literal offset.
 constexpr LdsDims kCompactDims = {30, 0, 40, 0, 0, 1};
+// the fused WBC entry under paper semantics: the same strides and virtual rows, plus what hard rows need -- the
+// least-squares rows of a level inside the active-set loop (kPBlRows) and 16 dependent columns
+// (reflector stride 32, not 25: the run-time level loop uses the Householder routines at their full vector length
+// of 32, whose readers take whole rows of the store; the specialised copies of the reference kernel read 24)
+constexpr int kPBlRows = 18, kPXrows = 16, kPLdv = 32, kPTv = 24 * kPLdv;
+constexpr LdsDims kPaperDims = {30, 0, 40, kPBlRows, 1, 2};
 
 __host__ __device__ inline LdsOff lds_offsets(const LdsDims &a)
 {
@@ -118,8 +124,8 @@ __host__ __device__ inline LdsOff lds_offsets(const LdsDims &a)
 		// G, TV and S are contiguous: the reference replay uses them as one scratch region, and reads
 		// of a masked-off tail of a TV row (tall levels: 32 rows x ld) stay inside the allocation
 		o.G = take(8 * kCGrows * ld);
-		o.TV = take(8 * kCTv);
-		o.S = take(8 * kCXrows * ld);
+		o.TV = take(8 * (a.compact == 2 ? kPTv : kCTv));
+		o.S = take(8 * (a.compact == 2 ? kPXrows : kCXrows) * ld);
 	}
 	o.g = take(8 * (P + 1));
 	o.vs = take(8 * (P + 1));  // optimal slack v* of every stored inequality row (Q3)
@@ -130,10 +136,10 @@ __host__ __device__ inline LdsOff lds_offsets(const LdsDims &a)
 		o.TV = take(8 * tv);
 		o.S = take(8 * ((CHUNK * SROW > XROWS * ld) ? CHUNK * SROW : XROWS * ld));
 	}
-	o.BL = take(a.compact ? 16 : 8 * ((mm && a.use_bl) ? mm : 1) * ld);
-	o.r0 = take(a.compact ? 16 : 8 * (mm + 1));
-	o.rho = take(a.compact ? 16 : 8 * (mm + 1));
-	o.a0 = take(a.compact ? 16 : 8 * (mm + 1));
+	o.BL = take(a.compact == 1 ? 16 : 8 * ((mm && a.use_bl) ? mm : 1) * ld);
+	o.r0 = take(a.compact == 1 ? 16 : 8 * (mm + 1));
+	o.rho = take(a.compact == 1 ? 16 : 8 * (mm + 1));
+	o.a0 = take(a.compact == 1 ? 16 : 8 * (mm + 1));
 	o.tau = take(8 * NR);
 	o.rdiag = take(8 * NR);
 	o.rhs = take(8 * kWave);
@@ -143,7 +149,7 @@ __host__ __device__ inline LdsOff lds_offsets(const LdsDims &a)
 	o.b3 = take(8 * 24);	   // fused WBC entry: right-hand side of the tracking level
 	o.pivlane = take(4 * NR);
 	o.W = take(4 * NR);
-	o.xlane = take(4 * (a.compact ? kCXrows : XROWS));
+	o.xlane = take(4 * (a.compact == 1 ? kCXrows : XROWS));
 	o.colpos = take(4 * kWave);
 	o.vlist = take(4 * kWave);
 	o.total = off + 256;  // readable tail: full-width (NR) vector reads may run past the last array
@@ -153,7 +159,7 @@ __host__ __device__ inline LdsOff lds_offsets(const LdsDims &a)
 __host__ __device__ inline LdsOff lds_offsets(const SolveArgs &a)
 {
 	if (a.compact)
-		return lds_offsets(kCompactDims);
+		return lds_offsets(a.compact == 2 ? kPaperDims : kCompactDims);
 	const LdsDims d = {a.n, a.ld, a.Ptot, a.mmax, a.use_bl, 0};
 	return lds_offsets(d);
 }
@@ -170,10 +176,10 @@ struct Lds {
 	unsigned long long *dbgp;  // HOQP_PROFILE builds: this instance's cycle-stamp slots (else null)
 };
 
-template <bool CK = false>  // CK: the kernel of the compact layout (offsets are literals)
+template <int CK = 0>  // CK: 1 / 2 = the kernels of the compact layouts (offsets are literals), 0 = from the arguments
 __device__ __forceinline__ Lds lds_bind(const SolveArgs &a, HOQP_LDS char *base)
 {
-	const LdsOff o = CK ? lds_offsets(kCompactDims) : lds_offsets(a);
+	const LdsOff o = CK == 1 ? lds_offsets(kCompactDims) : (CK == 2 ? lds_offsets(kPaperDims) : lds_offsets(a));
 	Lds l;
 	l.Z = (ldsd *)(base + o.Z);
 	l.x = (ldsd *)(base + o.x);
@@ -201,12 +207,13 @@ __device__ __forceinline__ Lds lds_bind(const SolveArgs &a, HOQP_LDS char *base)
 	l.colpos = (ldsi *)(base + o.colpos);
 	l.vlist = (ldsi *)(base + o.vlist);
 	l.ldv = LDV;
-	l.xrows = (CK || a.compact) ? kCXrows : XROWS;
-	if (CK || a.compact) {
+	const int cmode = CK ? CK : a.compact;
+	l.xrows = cmode == 1 ? kCXrows : (cmode == 2 ? kPXrows : XROWS);
+	if (cmode) {
 		l.rpZ = l.G;
 		l.rpZcap = kCReplayZ;
 		l.rpM = l.G + kCReplayZ;
-		l.rpMcap = kCGrows * kCLd + kCTv + kCXrows * kCLd - kCReplayZ;
+		l.rpMcap = kCGrows * kCLd + (cmode == 2 ? kPTv : kCTv) + l.xrows * kCLd - kCReplayZ;
 	} else {
 		l.rpZ = l.G;
 		l.rpZcap = (a.Ptot ? a.Ptot : 1) * a.ld;
@@ -1762,6 +1769,12 @@ __device__ __forceinline__ double eqp_step(const SolveArgs &a, const Lds &l, Lev
 		lims[sl] = has ? (isL ? rank : nz) : 0;
 		if (VG) {
 			vrs[sl] = vrow(vc, grow);
+			if (HARD && isL) {  // a least-squares row of the level: stored (BL), taken as it is
+				vrs[sl].p0 = l.BL + (q - w) * ld;
+				vrs[sl].p1 = vrs[sl].p0;
+				vrs[sl].s0 = 1.0;
+				vrs[sl].s1 = 0.0;
+			}
 			ld8(x[sl], vrs[sl].p0 + s);
 			ld8(xb[sl], vrs[sl].p1 + s);
 		} else {
@@ -2938,12 +2951,16 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l_in,
 	// the specialised level copies of the fused reference kernel run on the compact LDS layout (hoqp_solve.hpp
 	// head): compile-time leading dimensions; ldt: the projected rows of this level in TV
 	constexpr bool COMPACT = WBC && GATE && !HARD && KC >= 0;
-	const int n = uni(st.n), ld = COMPACT ? kCLd : a.ld;
-	const int ldt = (COMPACT && KC == 0) ? kCLd0 : ld;
+	// CP: the fused WBC entry under paper semantics (run-time level loop, hard rows): the same compact strides and
+	// virtual inequality rows; CV: either of the two
+	constexpr bool CP = WBC && !GATE && HARD;
+	constexpr bool CV = COMPACT || CP;
+	const int n = uni(st.n), ld = CV ? kCLd : a.ld;
+	const int ldt = (CV && k == 0) ? kCLd0 : ld;
 	Lds l = l_in;
-	if (COMPACT) {
-		l.ldv = (KC == 0) ? LDV : kCLdv;
-		l.xrows = kCXrows;
+	if (CV) {
+		l.ldv = (k == 0) ? LDV : (CP ? kPLdv : kCLdv);
+		l.xrows = CP ? kPXrows : kCXrows;
 	}
 	// the virtual rows of level 1 (compact layout; unused otherwise)
 	const VRowCtx vc = {l.G, l.Z, ld, wx.clp, wx.nc, a.wprm.friction_quirk, a.wprm.mu};
@@ -3019,7 +3036,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l_in,
 			if (k == 1) {
 				if (p > 0 && doD) {
 					load_bm(bm, n, nz, ld, l);
-					wbc_project_level1<COMPACT>(wx, a.wprm, jc, nz, ld, bm, dstG, l);
+					wbc_project_level1<CV>(wx, a.wprm, jc, nz, ld, bm, dstG, l);
 				}
 			} else if (m > 0 && doA) {
 				load_bm<kWbcKB>(bm, n, nz, ld, l);
@@ -3272,7 +3289,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l_in,
 		wave_sync();  // every column is in registers before TV is reused as the reflector store
 		rank = uni(panel_factor<COMPACT>(x, pos, nslot, 0, m, nz, 0, kEpsMach * (double)max(m, nz), l, HOQP_DBGP));
 		HOQP_STAMP(2);
-		if (COMPACT && KC == 0 && rank != kNB) {
+		if (CV && k == 0 && rank != kNB) {
 			// [M_fb, -J_c,fb^T] without full row rank (not a physical mass matrix): more than 24 free
 			// coordinates would be left, which the compact layout has no room for
 			st.status |= HOQP_STATUS_BASE_RANK;
@@ -3367,8 +3384,16 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l_in,
 				lds_set_identity(l.Z, n, ld);
 				wave_sync();
 			}
+		} else if (CP && k == 0) {
+			// (as the specialised level 0 above: Z = I is neither stored nor read -- a row of the compact layout
+			// has no room for 30 columns; rank == kNB here, the other case has bailed out)
+			wave_sync();
+			l.tmp[lane] = (lane < nz) ? yi : 0.0;
+			wave_sync();
+			rows_apply_reflectors_t<2, true, true>(l.Z, n, l.G, 0, ld, nz, 0, rank, l);
+			updated = true;
 		} else if (rank > 0)
-			rows_apply_reflectors(l.Z, n, l.G, Pg, ld, nz, 0, rank, l);
+			rows_apply_reflectors(l.Z, n, l.G, CP ? min(Pg, kCGrows) : Pg, ld, nz, 0, rank, l);  // (CP: the stored rows)
 		HOQP_STAMP(4);
 	}
 
@@ -3405,7 +3430,10 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l_in,
 		wave_sync();
 		l.tmp[lane] = (lane < nz) ? yi : 0.0;
 		wave_sync();
-		rows_dot<4>(l.G, P, ld, nz, l.tmp, l.c);
+		if (CP)
+			rows_dot_v<3>(vc, P, nz, l.tmp, l.c);
+		else
+			rows_dot<4>(l.G, P, ld, nz, l.tmp, l.c);
 		wave_sync();
 		const double gl = sel(lane < P, l.g[lane < P ? lane : 0]);
 		const double cl = sel(lane < P, l.c[lane < P ? lane : 0]);
@@ -3510,7 +3538,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l_in,
 					wave_sync();
 				}
 				if (!small)
-					pi = eqp_step<HARD, COMPACT, COMPACT>(a, l, st, ld, nz, rank, mB, w, nV, &k1, &overflow, vc);
+					pi = eqp_step<HARD, COMPACT, CV>(a, l, st, ld, nz, rank, mB, w, nV, &k1, &overflow, vc);
 				if (overflow) {
 					st.status |= HOQP_STATUS_WORKSPACE;
 					break;
@@ -3535,7 +3563,12 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l_in,
 					while (mk) {
 						int r = __ffsll((long long)mk) - 1;
 						mk &= mk - 1;
-						gi = fma(l.G[r * ld + lane], l.s[r], gi);
+						if (CV) {
+							const VRow vr = vrow(vc, r);
+							gi = fma(vval(vr, vr.p0[lane], vr.p1[lane]), l.s[r], gi);
+						} else {
+							gi = fma(l.G[r * ld + lane], l.s[r], gi);
+						}
 					}
 				}
 				const double gn = wave_max(fabs(gi));
@@ -3570,7 +3603,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l_in,
 			wave_sync();
 			l.tmp[lane] = (lane < nz) ? pi : 0.0;
 			wave_sync();
-			if (COMPACT)
+			if (CV)
 				rows_dot_v<3>(vc, Pn, nz, l.tmp, l.c);  // at most 40 rows, 12 of them stored
 			else if (WBC && KC >= 0)
 				rows_dot<3>(l.G, Pn, ld, nz, l.tmp, l.c);  // at most 40 rows
@@ -3694,8 +3727,15 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l_in,
 		// After the active-set loop l.s holds G y - g for every row (it moved with y, step by step), so the
 		// products G y need not be formed again; with rank == 0 the stored rows are not shifted either, and
 		// the update visits the rows of Z only (the all-soft level of the WBC: 30 rows instead of 70).
-		const bool from_s = qp_ran && rank == 0;
-		const int Pu = from_s ? 0 : Pg;
+		// (CP: G y is never formed again for the virtual rows -- after the loop it is in l.s, after a skipped loop
+		// in l.c from the check of the unconstrained optimum; the update shifts the 12 stored rows only)
+		const bool from_s = CP ? qp_ran : (qp_ran && rank == 0);
+		const bool from_c = CP && !qp_ran && skip_qp;
+		if (CP && Pg > 0 && !from_s && !from_c) {  // (not reached by the WBC hierarchy: kept rows, no free coordinate)
+			rows_dot_v<3>(vc, Pg, nz, l.tmp, l.c);
+			wave_sync();
+		}
+		const int Pu = CP ? ((Pg > 0 && rank > 0) ? kCGrows : 0) : (from_s ? 0 : Pg);
 		const int R = n + Pu;
 		if (updated)
 			;
@@ -3713,7 +3753,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l_in,
 		bool nonfinite = !isfinite(level_res2);
 		const double dq = q3 ? q3_delta() : 0.0;  // stored g goes back to each row's own slack
 		if (lane < Pg) {
-			double gi = (from_s ? 0.0 - l.s[lane] : l.g[lane] - l.S[n + lane]) - dq;
+			double gi = (from_s ? 0.0 - l.s[lane] : (CP ? l.g[lane] - l.c[lane] : l.g[lane] - l.S[n + lane])) - dq;
 			if (lane >= P) {
 				// v* = (D x - f)_+ ; the row becomes hard with rhs f + v* - D x
 				const double vopt = fmax(0.0, -gi);
@@ -3959,7 +3999,8 @@ __device__ __forceinline__ void hoqp_solve_body(const SolveArgs &a)
 {
 #ifdef __HIP_DEVICE_COMPILE__
 	extern __shared__ __align__(16) char smem[];
-	const Lds l = lds_bind<(WBC && GATE && !HARD)>(a, (HOQP_LDS char *)smem);
+	constexpr int CK = (WBC && GATE && !HARD) ? 1 : ((WBC && !GATE && HARD) ? 2 : 0);  // compact layouts
+	const Lds l = lds_bind<CK>(a, (HOQP_LDS char *)smem);
 	const int lane = lane_id();
 	const int inst = blockIdx.x;
 	if (inst >= a.batch)
@@ -3999,7 +4040,7 @@ __device__ __forceinline__ void hoqp_solve_body(const SolveArgs &a)
 	const int n = st.n, ld = a.ld;
 	// InitPrevProblemValuesToDefault, ho_qp_problem.cpp:119-128:  Z = I, x = 0  (the specialised level 0 of the
 	// fused reference kernel never reads Z = I: its projection is direct and its rotation generates the rows)
-	if (!(WBC && GATE && !HARD))
+	if (CK == 0)
 		lds_set_identity(l.Z, n, ld);
 	if (lane < NR)
 		l.x[lane] = 0.0;
@@ -4100,8 +4141,29 @@ __device__ __forceinline__ void hoqp_solve_body(const SolveArgs &a)
 			wave_sync();
 		}
 	} else {
-		for (int k = 0; k < a.L; ++k)
+		for (int k = 0; k < a.L && !st.bail; ++k)
 			run_level(std::integral_constant<int, -1>{}, k);
+		if (st.bail) {  // (paper-semantics WBC kernel: HOQP_STATUS_BASE_RANK, as above)
+			wave_sync();
+			if (lane < NR)
+				l.x[lane] = __builtin_nan("");
+			if (lane < a.L) {
+				const size_t o = (size_t)inst * a.L + lane;
+				if (a.out.level_res)
+					a.out.level_res[o] = __builtin_nan("");
+				if (a.out.iters)
+					a.out.iters[o] = 0;
+				if (a.out.nz_levels)
+					a.out.nz_levels[o] = 0;
+			}
+			if (a.out.x_levels)
+				for (int i = lane; i < a.L * a.n; i += kWave)
+					a.out.x_levels[(size_t)inst * a.L * a.n + i] = __builtin_nan("");
+			if (a.out.v)
+				for (int i = lane; i < a.Ptot; i += kWave)
+					a.out.v[(size_t)inst * a.Ptot + i] = __builtin_nan("");
+			wave_sync();
+		}
 	}
 	// ---- final x and the CheckSolutionValid flags (helper_functions.hpp:63-91) ----
 	double xi = (lane < n) ? l.x[lane] : 0.0;
@@ -4217,6 +4279,13 @@ __global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
 #ifndef HOQP_WBC_REF_WAVES
 #define HOQP_WBC_REF_WAVES 2
 #endif
+// The fused WBC entry under paper semantics: the compact strides and virtual rows with hard rows (kPaperDims).
+__attribute__((amdgpu_waves_per_eu(HOQP_WBC_REF_WAVES, HOQP_WBC_REF_WAVES)))
+__global__ void __launch_bounds__(kWave) hoqp_solve_wbc_paper_kernel(const SolveArgs a)
+{
+	hoqp_solve_body<false, true, true>(a);
+}
+
 __attribute__((amdgpu_waves_per_eu(HOQP_WBC_REF_WAVES, HOQP_WBC_REF_WAVES)))
 __global__ void __launch_bounds__(kWave) hoqp_solve_wbc_ref_kernel(const SolveArgs a)
 {

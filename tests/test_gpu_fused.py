@@ -35,7 +35,14 @@ def test_fused_equals_unfused(solver_factory, mode):
         assert np.all(a["status"] == 0) and np.all(b["status"] == 0)
         for key in ("x", "v", "level_res", "x_levels", "qdd"):
             if mode == "paper":
-                assert np.array_equal(a[key], b[key]), key
+                # levels 0 and 1 are the same arithmetic in both kernels; from level 2 on the fused kernel forms the
+                # friction rows from the rotated Z (virtual rows, compact layout) where the generic kernel rotates
+                # stored rows: equal in exact arithmetic, last digits differ
+                if key == "x_levels":
+                    assert np.array_equal(a[key][:, :2], b[key][:, :2]), key
+                big = np.maximum(1.0, np.abs(b[key]).reshape(b[key].shape[0], -1).max(axis=1))
+                err = np.abs(a[key] - b[key]).reshape(b[key].shape[0], -1).max(axis=1) / big
+                assert err.max() <= 1e-9, (key, err.max(), int(err.argmax()))
             else:
                 # reference semantics: the fused kernel takes the steps of the torque / friction level's QP
                 # through the 16 x 16 Gram system on the matrix cores (eqp_dual16), the generic kernel through
@@ -43,8 +50,13 @@ def test_fused_equals_unfused(solver_factory, mode):
                 # level starts from an x_1 that differs in the last digits
                 err = np.abs(a[key] - b[key]) / np.maximum(1.0, np.abs(b[key]))
                 assert err.max() <= 1e-9, (key, err.max())
-        for key in ("iters", "nz_levels"):
-            assert np.array_equal(a[key], b[key]), key
+        assert np.array_equal(a["nz_levels"], b["nz_levels"])
+        if mode == "paper":
+            # (an active-set path may take a tie the other way once the rows differ in their last digits)
+            differ = (a["iters"] != b["iters"]).any(axis=1)
+            assert differ.mean() <= 0.05, differ.sum()
+        else:
+            assert np.array_equal(a["iters"], b["iters"])
         assert np.abs(a["tau"] - b["tau"]).max() <= 1e-11 * max(1.0, np.abs(b["tau"]).max())
         scale = max(1.0, np.abs(data["M"]).max() * np.abs(b["x"]).max())
         assert np.abs(a["eq_res_max"] - b["eq_res_max"]).max() <= 1e-13 * scale
