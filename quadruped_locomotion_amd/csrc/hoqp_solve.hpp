@@ -102,9 +102,11 @@ struct LdsDims {
 constexpr LdsDims kCompactDims = {30, 0, 40, 0, 0, 1};
 // the fused WBC entry under paper semantics: the same strides and virtual rows, plus what hard rows need -- the
 // least-squares rows of a level inside the active-set loop (kPBlRows) and 16 dependent columns
-// (reflector stride 32, not 25: the run-time level loop uses the Householder routines at their full vector length
-// of 32, whose readers take whole rows of the store; the specialised copies of the reference kernel read 24)
-constexpr int kPBlRows = 18, kPXrows = 16, kPLdv = 32, kPTv = 24 * kPLdv;
+// (The Householder routines read whole rows of the reflector store at their compiled vector length: behind level 0
+// the paper kernel uses the 24-entry forms -- panel_factor<2 / 3>, rows_apply_reflectors_t<.., 6> -- so that the
+// store can keep the stride 25 of the reference kernel; with the 32-entry forms a row's tail is the next row's
+// head, which cost an afternoon.)
+constexpr int kPBlRows = 18, kPXrows = 16, kPLdv = kCLdv, kPTv = kCTv;
 constexpr LdsDims kPaperDims = {30, 0, 40, kPBlRows, 1, 2};
 
 __host__ __device__ inline LdsOff lds_offsets(const LdsDims &a)
@@ -462,18 +464,22 @@ __device__ __forceinline__ int panel_factor_t(double (&x)[NSP][NT], int (&pos)[N
 // VL: dispatch on the vector length class as well (the specialised level copies of the fused reference kernel;
 // in the general kernels the three extra copies of every step cost more than they save: paper semantics
 // 5.2 -> 4.4 M solves/s)
-template <int NS, bool VL>
+// VL (int): 0 = full length always; 1 = dispatch on 12 / 24 / 32; 2 = 24 or 32; 3 = 24 always (the caller knows that
+// nr <= 24: the levels behind level 0 of the paper-semantics WBC kernel, whose reflector store has stride 25)
+template <int NS, int VL>
 __device__ __forceinline__ int panel_factor_n(double (&x)[NSP][NT], int (&pos)[NSP], int qlo, int qhi, int nr, int k0,
 					      double rtol, const Lds &l, unsigned long long *dbgp)
 {
-	if (VL && nr <= 12)
+	if (VL == 3)
+		return panel_factor_t<NS, 6>(x, pos, qlo, qhi, nr, k0, rtol, l, dbgp);
+	if (VL == 1 && nr <= 12)
 		return panel_factor_t<NS, 3>(x, pos, qlo, qhi, nr, k0, rtol, l, dbgp);
-	if (VL && nr <= 24)
+	if (VL >= 1 && nr <= 24)
 		return panel_factor_t<NS, 6>(x, pos, qlo, qhi, nr, k0, rtol, l, dbgp);
 	return panel_factor_t<NS, NT>(x, pos, qlo, qhi, nr, k0, rtol, l, dbgp);
 }
 
-template <bool VL = false>
+template <int VL = 0>
 __device__ __forceinline__ int panel_factor(double (&x)[NSP][NT], int (&pos)[NSP], int nslot, int qlo, int qhi, int nr, int k0,
 				   double rtol, const Lds &l, unsigned long long *dbgp = nullptr)
 {
@@ -1735,7 +1741,7 @@ __device__ __forceinline__ int unp_index(bool unp, int &base)
 // Returns p_i in lane i; *k1_out = rank of the working set (reflectors [0,k1) stay in TV).
 // ---------------------------------------------------------------------------
 // VG: the rows of G are virtual (vrow; the fused reference kernel's level 1: no working set, no LS rows)
-template <bool HARD, bool VL = false, bool VG = false>
+template <bool HARD, int VL = 0, bool VG = false>
 __device__ __forceinline__ double eqp_step(const SolveArgs &a, const Lds &l, LevelState &st, int ld, int nz, int rank, int m,
 				  int w_in, int nV, int *k1_out, bool *overflow, const VRowCtx &vc)
 {
@@ -3178,7 +3184,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l_in,
 				t_upto(m, s, [&](int t, bool on) { x[sl][t] = sel(on && pos[sl] == -1, x[sl][t]); });
 			}
 			wave_sync();
-			const int rT = uni(panel_factor<(WBC && GATE && !HARD && KC >= 0)>(x, pos, nslot, 0, nz, m, 0, kEpsMach * (double)max(m, nz), l, HOQP_DBGP));
+			const int rT = uni(panel_factor<(COMPACT ? 1 : (CP ? 3 : 0))>(x, pos, nslot, 0, nz, m, 0, kEpsMach * (double)max(m, nz), l, HOQP_DBGP));
 			HOQP_STAMP(2);
 			if (rT < nz) {
 				tall = false;  // rank-deficient: project again, then the general path
@@ -3287,7 +3293,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l_in,
 			t_upto(nz, s, [&](int t, bool on) { x[sl][t] = sel(on && pos[sl] == -1, x[sl][t]); });
 		}
 		wave_sync();  // every column is in registers before TV is reused as the reflector store
-		rank = uni(panel_factor<COMPACT>(x, pos, nslot, 0, m, nz, 0, kEpsMach * (double)max(m, nz), l, HOQP_DBGP));
+		rank = uni(panel_factor<(COMPACT ? 1 : (CP ? 2 : 0))>(x, pos, nslot, 0, m, nz, 0, kEpsMach * (double)max(m, nz), l, HOQP_DBGP));
 		HOQP_STAMP(2);
 		if (CV && k == 0 && rank != kNB) {
 			// [M_fb, -J_c,fb^T] without full row rank (not a physical mass matrix): more than 24 free
@@ -3392,8 +3398,12 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l_in,
 			wave_sync();
 			rows_apply_reflectors_t<2, true, true>(l.Z, n, l.G, 0, ld, nz, 0, rank, l);
 			updated = true;
+		} else if (CP) {
+			// the 12 stored rows beside the rows of Z: at most 42 rows = three row slots, vectors of at most 24
+			if (rank > 0)
+				rows_apply_reflectors_t<3, false, false, 6>(l.Z, n, l.G, min(Pg, kCGrows), ld, nz, 0, rank, l);
 		} else if (rank > 0)
-			rows_apply_reflectors(l.Z, n, l.G, CP ? min(Pg, kCGrows) : Pg, ld, nz, 0, rank, l);  // (CP: the stored rows)
+			rows_apply_reflectors(l.Z, n, l.G, Pg, ld, nz, 0, rank, l);
 		HOQP_STAMP(4);
 	}
 
@@ -3538,7 +3548,7 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l_in,
 					wave_sync();
 				}
 				if (!small)
-					pi = eqp_step<HARD, COMPACT, CV>(a, l, st, ld, nz, rank, mB, w, nV, &k1, &overflow, vc);
+					pi = eqp_step<HARD, (COMPACT ? 1 : (CP ? 3 : 0)), CV>(a, l, st, ld, nz, rank, mB, w, nV, &k1, &overflow, vc);
 				if (overflow) {
 					st.status |= HOQP_STATUS_WORKSPACE;
 					break;
@@ -3739,6 +3749,8 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l_in,
 		const int R = n + Pu;
 		if (updated)
 			;
+		else if (CP)
+			level_update_t<3>(l, n, Pu, nz, rank, ld, HOQP_DBGP);
 		else if (R <= 32)
 			level_update_t<2>(l, n, Pu, nz, rank, ld, HOQP_DBGP);
 		else if (R <= 64)
