@@ -58,7 +58,7 @@ extern "C" {
 					  both sides) the bit means eps > 1e-4 d^2.  Informational: x is the solver's
 					  best answer, every other output is consistent with it. */
 #define HOQP_STATUS_BAD_EXTENT 0x20	 /* n_inst / m_inst / p_inst beyond the storage extent: clamped to it */
-#define HOQP_STATUS_BASE_RANK 0x40	 /* hoqp_solve_wbc_batched, reference semantics: [M_fb, -J_c,fb^T] (the floating-base
+#define HOQP_STATUS_BASE_RANK 0x40	 /* hoqp_solve_wbc_batched (either semantics; compact LDS layouts): [M_fb, -J_c,fb^T] (the floating-base
 					  * block of ho_qp_controller.cpp:351-366) has rank < 6 -- not a physical mass matrix.
 					  * The state is not solved (x, tau, slacks = NaN); hoqp_solve_wbc_unfused takes any state */
 

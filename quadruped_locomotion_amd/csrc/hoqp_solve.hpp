@@ -3990,19 +3990,22 @@ __device__ __forceinline__ void wbc_tail(const SolveArgs &a, const Lds &l, const
 	const double er3 = wave_max(e3);
 	// level 4
 	const double er4 = wave_max(lane < m2 ? fabs(l.x[kNU + (lane < m2 ? lane : 0)]) : 0.0);
+	// The maxima above are fmax reductions, which drop a NaN: an instance whose x is not finite (or that was not
+	// solved at all, HOQP_STATUS_BASE_RANK) must never come out "valid" -- its residuals are NaN, its flags 0.
+	const bool unsolved = (status & (HOQP_STATUS_NONFINITE | HOQP_STATUS_BASE_RANK)) != 0;
 	if (lane < 5) {
 		const double er = lane == 0 ? er0 : (lane == 2 ? er2 : (lane == 3 ? er3 : (lane == 4 ? er4 : 0.0)));
 		const double iv = lane == 1 ? iv1 : 0.0;
 		const size_t o = (size_t)inst * 5 + lane;
 		if (a.out.flags)
-			a.out.flags[o] = (er <= 1e-7 && (lane != 1 || iv <= 0.0)) ? 1 : 0;
+			a.out.flags[o] = (!unsolved && er <= 1e-7 && (lane != 1 || iv <= 0.0)) ? 1 : 0;
 		if (a.out.eq_res_max)
-			a.out.eq_res_max[o] = er;
+			a.out.eq_res_max[o] = unsolved ? __builtin_nan("") : er;
 		if (a.out.ineq_viol_max)
-			a.out.ineq_viol_max[o] = iv;
+			a.out.ineq_viol_max[o] = unsolved ? __builtin_nan("") : iv;
 	}
 	if (lane == 0 && a.out.active_mask)
-		a.out.active_mask[inst] = act;
+		a.out.active_mask[inst] = unsolved ? 0ull : act;
 }
 #endif  // __HIP_DEVICE_COMPILE__
 
