@@ -3435,6 +3435,8 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l_in,
 		wave_sync();
 	}
 	bool skip_qp = false;
+	double y0i = 0.0;
+	bool y0_ok = false;
 	if (tryfast && have_y0) {
 		// does any stored row object to the unconstrained optimum?
 		wave_sync();
@@ -3449,6 +3451,8 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l_in,
 		const double cl = sel(lane < P, l.c[lane < P ? lane : 0]);
 		skip_qp = __ballot(lane < P && cl - gl > 1e-11 * (1.0 + fabs(gl))) == 0ull;
 		if (!skip_qp) {
+			y0i = yi;  // the loop's first step from y = 0 with an empty working set is this vector (below)
+			y0_ok = true;
 			yi = 0.0;
 			level_res2 = 0.0;
 		}
@@ -3528,7 +3532,13 @@ __device__ __forceinline__ void solve_level(const SolveArgs &a, const Lds &l_in,
 			bool overflow = false;
 			HOQP_STAMP(5);
 			double pi = 0.0;
-			if (!(prev_full && vmask == prev_vmask)) {
+			if (HARD && y0_ok && !need_p1 && iters == 0 && w == 0 && nV == 0) {
+				// Nothing active, nothing violated, y = 0: the equality-constrained step is the minimum-norm
+				// minimiser of |B0 p - r0| -- the unconstrained optimum y0 that was computed and found infeasible
+				// a moment ago.  No factorization of the (triangular) least-squares block for a known answer.
+				pi = y0i;
+				k1 = 0;
+			} else if (!(prev_full && vmask == prev_vmask)) {
 				wave_sync();
 				bool small = !HARD && mB == 0 && nV >= 1 && nV <= 8 && nV <= nz && eqp_dual8<COMPACT>(l, nz, nV, ld, &pi, vc);
 #ifdef HOQP_PROFILE
