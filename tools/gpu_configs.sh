@@ -9,6 +9,7 @@ run c2_ref
 run c2_paper --mode paper
 run c3_trot65536_ref --batch 65536 --contact trot --seed 2345
 run c3_trot65536_paper --batch 65536 --contact trot --seed 2345 --mode paper
+run c2_paper65536 --batch 65536 --mode paper
 run c5_three4096_paper --contact three --seed 4567 --mode paper --mu 0.2 --tau-max 40
 run c5_three65536_paper --batch 65536 --contact three --seed 4567 --mode paper --mu 0.2 --tau-max 40
 run c5_three4096_paper_defaults --contact three --seed 4567 --mode paper
