@@ -38,6 +38,9 @@ constexpr int XROWS = 16; // dumped unpivoted columns (rank-deficient least squa
 // reference replay updates its basis chain in place inside G + TV + S.
 // A state whose floating-base block [M_fb, -J_c,fb^T] has rank < 6 (impossible for a physical mass matrix) does
 // not fit and is reported as HOQP_STATUS_BASE_RANK instead of being solved.
+// The fused WBC kernel under paper semantics (SolveArgs::compact == 2, kPaperDims below, 25,472 B: six workgroups
+// per CU) uses the same strides and virtual rows; its stored rows live on as hard rows of levels 2..4, so it adds
+// the least-squares rows of a level inside the active-set loop and 16 dependent columns (solve_level: CP).
 constexpr int kCLd = 25;	 // Z, G, X, projected rows of levels >= 1
 constexpr int kCLd0 = 31;	 // projected rows of level 0 (6 x n)
 constexpr int kCLdv = 25;	 // reflector store, levels >= 1
