@@ -542,6 +542,9 @@ static int launch_solve(hoqp_handle *h, SolveArgs &a, hipStream_t s, bool wbc, b
 	void (*kern)(const SolveArgs);
 	if (wbc)
 		kern = !a.any_hard ? hoqp_solve_wbc_ref_kernel : hoqp_solve_wbc_paper_kernel;
+	else if (lds * 6 <= 160 * 1024)  // six workgroups fit a CU: the two-waves-per-SIMD builds (hoqp_solve.hpp)
+		kern = !a.any_hard ? hoqp_solve_kernel_w2<true, false>
+				   : (a.gate_prior ? hoqp_solve_kernel_w2<true, true> : hoqp_solve_kernel_w2<false, true>);
 	else
 		kern = !a.any_hard ? hoqp_solve_kernel<true, false, false>
 				   : (a.gate_prior ? hoqp_solve_kernel<true, true, false> : hoqp_solve_kernel<false, true, false>);

@@ -4307,6 +4307,17 @@ __global__ void __launch_bounds__(kWave) hoqp_solve_kernel(const SolveArgs a)
 #ifndef HOQP_WBC_REF_WAVES
 #define HOQP_WBC_REF_WAVES 2
 #endif
+// The generic instantiations once more under the register budget of two waves per SIMD, for hierarchies whose
+// LDS footprint lets at least six workgroups share a CU (launch_solve picks: <= 27,306 B).  A small hierarchy
+// (n = 8 ... 20) runs 1.5 - 1.65 x faster this way; a 30-variable one with stored rows (38 KB) stays at one wave
+// per SIMD whatever its registers and would only pay the limit's spills (-7 %), hence two sets.
+template <bool GATE, bool HARD>
+__attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(kWave) hoqp_solve_kernel_w2(const SolveArgs a)
+{
+	hoqp_solve_body<GATE, HARD, false>(a);
+}
+
 // The fused WBC entry under paper semantics: the compact strides and virtual rows with hard rows (kPaperDims).
 __attribute__((amdgpu_waves_per_eu(HOQP_WBC_REF_WAVES, HOQP_WBC_REF_WAVES)))
 __global__ void __launch_bounds__(kWave) hoqp_solve_wbc_paper_kernel(const SolveArgs a)
